@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.golden and *.txt inputs (development container only).
+
+Needs `make -C oracle ref` (builds oracle/_ref/{ref_dump,ref_unit,InStruct_ref} from the real
+reference sources under /root/reference).  The golden trajectory files hold, after every sweep
+of every iteration, FNV-64 hashes of z / allele counts / generation / freq / qq, the RNG seed
+triple and hex-float scalars as produced by the reference's own update_P / update_S_POP /
+update_G / update_ZQ / update_alpha / cal_lkh (see oracle/ref_dump.c, oracle/dump_fmt.h).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from instruct_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+# name: (N, L, K, n_alleles, missing, u, b, t, c, e, y, r, j, seeds, mode, pf, detail, commit_text)
+CASES = {
+    "c1":       (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 1, 1, 5, 5, (13, 4, 1972), 2, 1, 10, True),
+    "c1_miss":  (50, 100, 3, 2, 0.05, 200, 100, 10, 1, 1, 1, 5, 5, (13, 4, 1972), 2, 0, 10, True),
+    "c1_a3":    (50, 100, 3, 3, 0.02, 200, 100, 10, 1, 1, 1, 5, 5, (14, 5, 1973), 2, 1, 10, True),
+    "c1_e0":    (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 0, 1, 5, 5, (13, 4, 1972), 2, 0, 10, False),
+    "c1_y0":    (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 1, 0, 5, 5, (13, 4, 1972), 2, 0, 10, False),
+    "c1_mode1": (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 1, 1, 5, 5, (13, 4, 1972), 1, 0, 10, False),
+    "c1_c2":    (50, 100, 3, 2, 0.00, 120, 60, 10, 2, 1, 1, 6, 5, (21, 7, 1999), 2, 0, 0, False),
+    "c2s":      (200, 300, 5, 2, 0.01, 40, 20, 5, 1, 1, 1, 4, 4, (13, 4, 1972), 2, 0, 0, False),
+    "c2s_a4":   (120, 150, 4, 4, 0.03, 40, 20, 5, 1, 1, 1, 4, 4, (15, 6, 1974), 2, 0, 0, False),
+}
+
+
+def data_for(name):
+    N, L, K, A, miss = CASES[name][:5]
+    base = {"c1_e0": "c1", "c1_y0": "c1", "c1_mode1": "c1", "c1_c2": "c1"}.get(name, name)
+    seed = 20260101 + sorted(CASES).index(base)
+    return synth.raw_alleles(N, L, K, 2, A, miss, seed)
+
+
+def main():
+    subprocess.check_call([os.path.join(REF, "ref_unit"), os.path.join(HERE, "unit_random.golden")])
+    for name, cfg in CASES.items():
+        N, L, K, A, miss, u, b, t, c, e, y, r, j, seeds, mode, pf, detail, commit_text = cfg
+        raw = data_for(name)
+        txt = os.path.join(HERE, name + ".txt") if commit_text else os.path.join("/tmp", name + ".txt")
+        synth.write_text_diploid(txt, raw)
+        out = os.path.join(HERE, name + ".golden")
+        args = [os.path.join(REF, "ref_dump"), txt, out] + [str(x) for x in
+                (K, N, L, u, b, t, c, e, y, r, j, seeds[0], seeds[1], seeds[2], mode, pf, detail)]
+        with open(os.devnull, "w") as devnull:
+            subprocess.check_call(args, stdout=devnull)
+        print(name, os.path.getsize(out), "bytes")
+    # end-to-end reference CLI output for the drop-in test (result file at %.3f)
+    txt = os.path.join(HERE, "c1.txt")
+    outp = os.path.join(HERE, "c1_cli_output.txt")
+    cmd = [os.path.join(REF, "InStruct_ref"), "-d", txt, "-o", outp, "-K", "3", "-L", "100", "-N", "50", "-p", "2",
+           "-u", "200", "-b", "100", "-t", "10", "-c", "2", "-v", "2", "-g", "1", "-r", "5", "-j", "5",
+           "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "1"]
+    with open(os.devnull, "w") as devnull:
+        subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
+
+
+if __name__ == "__main__":
+    main()
