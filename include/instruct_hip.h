@@ -1,0 +1,132 @@
+/*
+ * instruct_hip.h -- C ABI of the MI355X-native InStruct MCMC hot path (libinstruct_hip.so).
+ *
+ * This is the drop-in boundary for the per-iteration sampler of slowkoni/InStruct: every entry
+ * point below replaces one function of the reference's mcmc.c (cited per declaration) and takes
+ * plain pointers and sizes only.  The reference driver keeps calling
+ *     CHAIN mcmc_updating(SEQDATA, INIT, int chn, CONVG *)   (mcmc.h:56, call sites InStruct.c:184,565)
+ *     void  free_chain(CHAIN *, SEQDATA)                     (mcmc.h:57)
+ * which instruct_amd/host/mcmc_hip.c implements on top of this ABI with the reference's struct
+ * layouts (see INTEGRATION.md for the link line a maintainer adds).
+ *
+ * Data layout handed over at context creation (the reference's in-memory genotype layout,
+ * data_interface.h:10-56): allele codes int32 [N][L][P] (0..allelenum[j]-1), missindx int32
+ * [N][L] (1 = locus missing for that individual), allelenum int32 [L].  On the device genotypes
+ * and ancestry assignments Z are packed to one byte per allele copy, N x L-major.
+ *
+ * Errors: every function returns 0 on success, nonzero on failure; isg_last_error() returns the
+ * message (the mcmc_updating shim turns it into the reference's nrerror() convention,
+ * nrutil.c:9-16).  There is no CPU fallback: without a usable gfx950 device isg_ctx_create fails.
+ *
+ * RNG schedules (cfg.rng_sched):
+ *   ISG_SCHED_REPLAY  the single Wichmann-Hill stream of random.c:14-47 is consumed at exactly
+ *                     the positions the reference consumes it (Z assignments, allele counts,
+ *                     generations and seeds are bit-identical to the reference run);
+ *   ISG_SCHED_KEYED   same generator, same samplers, but each consumer starts at a stream
+ *                     position that only depends on (iteration, phase, index) -- "keyed layout"
+ *                     below -- so that all consumers run concurrently.
+ */
+#ifndef INSTRUCT_HIP_H
+#define INSTRUCT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISG_SCHED_REPLAY 0
+#define ISG_SCHED_KEYED 1
+
+typedef struct isg_ctx isg_ctx;
+
+typedef struct {
+	int32_t N;         /* individuals            SEQDATA.totalsize */
+	int32_t L;         /* polymorphic loci       SEQDATA.locinum   */
+	int32_t P;         /* ploidy (2)             SEQDATA.ploid     */
+	int32_t K;         /* clusters (<= 32)       SEQDATA.popnum    */
+	int32_t mode;      /* 1 admixture, 2 population selfing rates (InStruct.c:58, mcmc.c:63-87) */
+	int32_t type_freq; /* -y (InStruct.c:46) */
+	int32_t back_refl; /* -e (InStruct.c:45) */
+	int32_t rng_sched; /* ISG_SCHED_* */
+	int32_t device;    /* HIP device ordinal */
+	int32_t reserved[7];
+} isg_config;
+
+/* problem upload + device state allocation (replaces allocate_node, mcmc.c:506-546) */
+int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, const int32_t *geno, const int32_t *missindx, isg_ctx **out);
+void isg_ctx_destroy(isg_ctx *ctx);
+const char *isg_last_error(void);
+
+/* RNG stream shared with the driver (random.c:50-63 setseeds/printseeds; ran1 random.c:34-47) */
+int isg_set_seeds(isg_ctx *ctx, long s1, long s2, long s3);
+int isg_get_seeds(isg_ctx *ctx, long seeds[3]);
+double isg_ran1(isg_ctx *ctx);
+
+/* chain set-up: initial_chn's alpha draw (mcmc.c:479), generation / selfing-rate initialisation
+ * (mcmc.c:196-205) and update_ZQ(init_flag = 1) (mcmc.c:206).  initd: K floats (INIT.initd[chn]) */
+int isg_chain_init(isg_ctx *ctx, const float *initd);
+
+/* one call per reference sweep */
+int isg_update_P(isg_ctx *ctx);                 /* mcmc.c:799-861  */
+int isg_update_S_POP(isg_ctx *ctx);             /* mcmc.c:913-983  */
+int isg_update_G(isg_ctx *ctx);                 /* mcmc.c:1053-1091 (+ log_ld_indv :1726-1773) */
+int isg_update_ZQ(isg_ctx *ctx, int init_flag); /* mcmc.c:1122-1203 */
+int isg_update_alpha(isg_ctx *ctx);             /* mcmc.c:1244-1263 */
+int isg_cal_lkh(isg_ctx *ctx);                  /* mcmc.c:1916-1942 */
+int isg_iteration(isg_ctx *ctx);                /* the loop body mcmc.c:210-215 (mode 2) / 152-155 (mode 1) */
+int isg_run(isg_ctx *ctx, long n_iterations);
+
+/* allele counts seqpop[K][L][Amax] of the current Z (the count nest mcmc.c:810-845) */
+int isg_count_alleles(isg_ctx *ctx, int32_t *counts);
+
+/* state download, reference layouts (UPMCMC, mcmc.h:12-27) */
+int isg_get_z(isg_ctx *ctx, int32_t *z);                 /* [N][L][P]; -1 where the locus is unused */
+int isg_get_freq(isg_ctx *ctx, double *freq);            /* [K][L][Amax] */
+int isg_get_qq(isg_ctx *ctx, double *qq);                /* [N][K] */
+int isg_get_qqnum(isg_ctx *ctx, double *qqnum);          /* [N][K] */
+int isg_get_generation(isg_ctx *ctx, int32_t *gen);      /* [N] */
+int isg_get_self_rates(isg_ctx *ctx, double *s);         /* [K] */
+int isg_get_state(isg_ctx *ctx, int32_t *state);         /* [K] (-e 0) */
+int isg_get_indvlkh(isg_ctx *ctx, double *indvlkh);      /* [N] */
+int isg_get_alpha(isg_ctx *ctx, double *alpha);
+int isg_get_totallkh(isg_ctx *ctx, double *totallkh);
+int isg_get_amax(isg_ctx *ctx, int32_t *amax);
+
+/* state upload (tests; restarting a chain from saved state) */
+int isg_set_z(isg_ctx *ctx, const int32_t *z);
+int isg_set_freq(isg_ctx *ctx, const double *freq);
+int isg_set_qq(isg_ctx *ctx, const double *qq);
+int isg_set_generation(isg_ctx *ctx, const int32_t *gen);
+int isg_set_self_rates(isg_ctx *ctx, const double *s);
+int isg_set_alpha(isg_ctx *ctx, double alpha);
+
+/*
+ * keyed layout, positions counted in uniforms from the chain origin (the stream state when
+ * isg_chain_init is entered):
+ *   0                     alpha
+ *   1 + 2 i               generation init of individual i
+ *   ZI0 + i SZ            ZQ(init) of individual i           ZI0 = 1 + 2N, SZ = P L + 16 K + 16
+ *   iteration t base B = B0 + t BLK,  B0 = ZI0 + N SZ
+ *   B + (k L + j) SP      update_P Dirichlet (k, j)          SP = 16 Amax + 16
+ *   B + offS              update_S_POP                        offS = K L SP
+ *   B + offG + 2 i        update_G individual i              offG = offS + 4 K
+ *   B + offZ + i SZ       update_ZQ individual i             offZ = offG + 2 N
+ *   B + offA              update_alpha                        offA = offZ + N SZ;  BLK = offA + 4
+ * out[9] = {SP, SZ, ZI0, B0, offS, offG, offZ, offA, BLK}
+ */
+int isg_keyed_layout(isg_ctx *ctx, uint64_t out[9]);
+
+/* per-kernel device timing with HIP events on the launch stream (bench.py roofline) */
+int isg_profile_enable(isg_ctx *ctx, int on);
+int isg_profile_count(isg_ctx *ctx);
+int isg_profile_get(isg_ctx *ctx, int idx, char *name, int name_cap, double *total_ms, long *launches);
+int isg_profile_reset(isg_ctx *ctx);
+
+/* one-shot exchange of the per-chain log-likelihood samples for the Gelman-Rubin check
+ * (CONVG.convg_ld, mcmc.c:223-224; check_converg.c:100-153): see instruct_amd/host */
+double isg_gelman_rubin(const double *vec, int numchains, int totrep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,75 @@
+"""Builds the native pieces in-tree (no JIT cache): the HIP library for gfx950 and the C host shim.
+
+    python -m instruct_amd.build            # libinstruct_hip.so + libinstruct_mcmc.so
+    python -m instruct_amd.build --oracle   # also oracle/liborc.so (+ oracle/_ref when /root/reference exists)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIB_HIP = os.path.join(PKG, "libinstruct_hip.so")
+LIB_MCMC = os.path.join(PKG, "libinstruct_mcmc.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, **kw):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, **kw)
+
+
+def hipcc():
+    for c in ("hipcc", "/opt/rocm/bin/hipcc"):
+        p = shutil.which(c)
+        if p:
+            return p
+    raise RuntimeError("hipcc not found")
+
+
+def build_hip(force=False):
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "instruct_hip.h")]
+    if force or _newer(LIB_HIP, srcs):
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+              "-Wall", "-Wno-unused-function", "-o", LIB_HIP, os.path.join(CSRC, "isg_hip.hip")])
+    return LIB_HIP
+
+
+def build_host(force=False):
+    src = os.path.join(HOST, "mcmc_hip.c")
+    if not os.path.exists(src):
+        return None
+    srcs = [os.path.join(HOST, f) for f in os.listdir(HOST)] + [os.path.join(ROOT, "include", "instruct_hip.h")]
+    if force or _newer(LIB_MCMC, srcs):
+        _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
+              "-o", LIB_MCMC, src, os.path.join(HOST, "nr_compat.c"),
+              "-L", PKG, "-linstruct_hip", "-Wl,-rpath,$ORIGIN", "-lm"])
+    return LIB_MCMC
+
+
+def build_oracle():
+    _run(["make", "-C", os.path.join(ROOT, "oracle"), "all"])
+    if os.path.isdir("/root/reference"):
+        _run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+
+
+def main(argv):
+    build_hip("--force" in argv)
+    build_host("--force" in argv)
+    if "--oracle" in argv:
+        build_oracle()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

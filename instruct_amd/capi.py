@@ -1,0 +1,225 @@
+"""ctypes binding of the C ABI in include/instruct_hip.h (libinstruct_hip.so).
+
+Host-side mirror of the reference's sampler interface for one chain: method names follow the
+reference functions (mcmc.c) each entry point replaces.  There is no CPU fallback: constructing a
+:class:`HipChain` without a usable HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libinstruct_hip.so")
+
+SCHED_REPLAY, SCHED_KEYED = 0, 1
+
+EXPORTS = [
+    "isg_ctx_create", "isg_ctx_destroy", "isg_last_error", "isg_set_seeds", "isg_get_seeds", "isg_ran1",
+    "isg_chain_init", "isg_update_P", "isg_update_S_POP", "isg_update_G", "isg_update_ZQ", "isg_update_alpha",
+    "isg_cal_lkh", "isg_iteration", "isg_run", "isg_count_alleles", "isg_get_z", "isg_get_freq", "isg_get_qq",
+    "isg_get_qqnum", "isg_get_generation", "isg_get_self_rates", "isg_get_state", "isg_get_indvlkh",
+    "isg_get_alpha", "isg_get_totallkh", "isg_get_amax", "isg_set_z", "isg_set_freq", "isg_set_qq",
+    "isg_set_generation", "isg_set_self_rates", "isg_set_alpha", "isg_keyed_layout", "isg_profile_enable",
+    "isg_profile_count", "isg_profile_get", "isg_profile_reset", "isg_gelman_rubin",
+]
+
+
+class IsgConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "L", "P", "K", "mode", "type_freq", "back_refl", "rng_sched", "device")] + [
+        ("reserved", C.c_int32 * 7)]
+
+
+_lib = None
+
+
+def load():
+    """Loads libinstruct_hip.so (raises if it has not been built -- there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run `python -m instruct_amd.build` (HIP extension is mandatory)")
+        lib = C.CDLL(LIB_PATH)
+        lib.isg_last_error.restype = C.c_char_p
+        lib.isg_ran1.restype = C.c_double
+        lib.isg_ran1.argtypes = [C.c_void_p]
+        lib.isg_gelman_rubin.restype = C.c_double
+        lib.isg_gelman_rubin.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.isg_set_seeds.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long]
+        lib.isg_set_alpha.argtypes = [C.c_void_p, C.c_double]
+        lib.isg_run.argtypes = [C.c_void_p, C.c_long]
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class IsgError(RuntimeError):
+    pass
+
+
+class HipChain:
+    """One MCMC chain on one MI355X (UPMCMC state device resident)."""
+
+    def __init__(self, geno, allelenum, missindx, K, mode=2, type_freq=1, back_refl=1, rng_sched=SCHED_REPLAY, device=0):
+        self.lib = load()
+        geno = np.ascontiguousarray(geno, dtype=np.int32)
+        self.N, self.L, self.P = geno.shape
+        self.K = K
+        allelenum = np.ascontiguousarray(allelenum, dtype=np.int32)
+        missindx = np.ascontiguousarray(missindx, dtype=np.int32)
+        cfg = IsgConfig(self.N, self.L, self.P, K, mode, type_freq, back_refl, rng_sched, device)
+        h = C.c_void_p()
+        self._chk(self.lib.isg_ctx_create(C.byref(cfg), _ptr(allelenum), _ptr(geno), _ptr(missindx), C.byref(h)))
+        self.h = h
+        a = C.c_int32()
+        self.lib.isg_get_amax(self.h, C.byref(a))
+        self.Amax = a.value
+        self.mode = mode
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise IsgError(self.lib.isg_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.isg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- RNG (random.c:50-63)
+    def setseeds(self, s1, s2, s3):
+        self._chk(self.lib.isg_set_seeds(self.h, s1, s2, s3))
+
+    def seeds(self):
+        s = (C.c_long * 3)()
+        self._chk(self.lib.isg_get_seeds(self.h, s))
+        return tuple(s)
+
+    def ran1(self):
+        return self.lib.isg_ran1(self.h)
+
+    # --- sweeps (mcmc.c)
+    def chain_init(self, initd):
+        v = np.ascontiguousarray(initd, dtype=np.float32)
+        self._chk(self.lib.isg_chain_init(self.h, _ptr(v)))
+
+    def update_P(self):
+        self._chk(self.lib.isg_update_P(self.h))
+
+    def update_S_POP(self):
+        self._chk(self.lib.isg_update_S_POP(self.h))
+
+    def update_G(self):
+        self._chk(self.lib.isg_update_G(self.h))
+
+    def update_ZQ(self, init_flag=0):
+        self._chk(self.lib.isg_update_ZQ(self.h, init_flag))
+
+    def update_alpha(self):
+        self._chk(self.lib.isg_update_alpha(self.h))
+
+    def cal_lkh(self):
+        self._chk(self.lib.isg_cal_lkh(self.h))
+
+    def iteration(self):
+        self._chk(self.lib.isg_iteration(self.h))
+
+    def run(self, n):
+        self._chk(self.lib.isg_run(self.h, n))
+
+    # --- state
+    def _get(self, fn, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self._chk(getattr(self.lib, fn)(self.h, _ptr(out)))
+        return out
+
+    def count_alleles(self):
+        return self._get("isg_count_alleles", (self.K, self.L, self.Amax), np.int32)
+
+    def z(self):
+        return self._get("isg_get_z", (self.N, self.L, self.P), np.int32)
+
+    def freq(self):
+        return self._get("isg_get_freq", (self.K, self.L, self.Amax), np.float64)
+
+    def qq(self):
+        return self._get("isg_get_qq", (self.N, self.K), np.float64)
+
+    def qqnum(self):
+        return self._get("isg_get_qqnum", (self.N, self.K), np.float64)
+
+    def generation(self):
+        return self._get("isg_get_generation", (self.N,), np.int32)
+
+    def self_rates(self):
+        return self._get("isg_get_self_rates", (self.K,), np.float64)
+
+    def state(self):
+        return self._get("isg_get_state", (self.K,), np.int32)
+
+    def indvlkh(self):
+        return self._get("isg_get_indvlkh", (self.N,), np.float64)
+
+    def alpha(self):
+        v = C.c_double()
+        self._chk(self.lib.isg_get_alpha(self.h, C.byref(v)))
+        return v.value
+
+    def totallkh(self):
+        v = C.c_double()
+        self._chk(self.lib.isg_get_totallkh(self.h, C.byref(v)))
+        return v.value
+
+    def set_z(self, z):
+        self._chk(self.lib.isg_set_z(self.h, _ptr(np.ascontiguousarray(z, dtype=np.int32))))
+
+    def set_freq(self, f):
+        self._chk(self.lib.isg_set_freq(self.h, _ptr(np.ascontiguousarray(f, dtype=np.float64))))
+
+    def set_qq(self, q):
+        self._chk(self.lib.isg_set_qq(self.h, _ptr(np.ascontiguousarray(q, dtype=np.float64))))
+
+    def set_generation(self, g):
+        self._chk(self.lib.isg_set_generation(self.h, _ptr(np.ascontiguousarray(g, dtype=np.int32))))
+
+    def set_self_rates(self, s):
+        self._chk(self.lib.isg_set_self_rates(self.h, _ptr(np.ascontiguousarray(s, dtype=np.float64))))
+
+    def set_alpha(self, a):
+        self._chk(self.lib.isg_set_alpha(self.h, float(a)))
+
+    def keyed_layout(self):
+        out = (C.c_uint64 * 9)()
+        self._chk(self.lib.isg_keyed_layout(self.h, out))
+        return tuple(out)
+
+    # --- profiling
+    def profile(self, on=True):
+        self.lib.isg_profile_enable(self.h, 1 if on else 0)
+
+    def profile_reset(self):
+        self.lib.isg_profile_reset(self.h)
+
+    def profile_results(self):
+        res = {}
+        for i in range(self.lib.isg_profile_count(self.h)):
+            name = C.create_string_buffer(64)
+            ms, n = C.c_double(), C.c_long()
+            self._chk(self.lib.isg_profile_get(self.h, i, name, 64, C.byref(ms), C.byref(n)))
+            res[name.value.decode()] = (ms.value, n.value)
+        return res
+
+
+def gelman_rubin(vec, numchains, totrep):
+    v = np.ascontiguousarray(vec, dtype=np.float64)
+    return load().isg_gelman_rubin(_ptr(v), numchains, totrep)

@@ -1,0 +1,98 @@
+/*
+ * isg_wh.h -- Wichmann-Hill generator as a random-access ("counter based") stream.
+ *
+ * The reference draws every uniform from one process-global stream (random.c:14-47):
+ *     s1 = 171*s1 % 30269;  s2 = 172*s2 % 30307;  s3 = 170*s3 % 30323;
+ *     u  = fmod(s1/30269.0 + s2/30307.0 + s3/30323.0, 1.0)
+ * Each component is a multiplicative LCG modulo a prime, so the state n draws after a known
+ * state is s_r * a_r^n mod m_r, and a_r^n only depends on n mod (m_r - 1).  That turns the
+ * stream into a function position -> uniform which every GPU lane evaluates independently:
+ * one two-level table lookup to land on its first position, then plain stepping.
+ *
+ * Host and device use the same code (the host tracks the stream position between kernels).
+ */
+#ifndef ISG_WH_H
+#define ISG_WH_H
+#include <stdint.h>
+#include "isg_math.h"
+
+#define ISG_M1 30269u
+#define ISG_M2 30307u
+#define ISG_M3 30323u
+#define ISG_A1 171u
+#define ISG_A2 172u
+#define ISG_A3 170u
+
+typedef struct {
+	uint32_t s1, s2, s3;
+} isg_wh;
+
+/* a^lo (lo < 256) and a^(256*hi) (hi < 119) for the three generators; filled by isg_wh_tables_init */
+typedef struct {
+	uint16_t lo[3][256];
+	uint16_t hi[3][120];
+} isg_wh_tables;
+
+static inline void isg_wh_tables_init(isg_wh_tables *t)
+{
+	static const uint32_t m[3] = {ISG_M1, ISG_M2, ISG_M3}, a[3] = {ISG_A1, ISG_A2, ISG_A3};
+	int r, i;
+	for (r = 0; r < 3; r++) {
+		uint32_t v = 1, b;
+		for (i = 0; i < 256; i++) { t->lo[r][i] = (uint16_t)v; v = v * a[r] % m[r]; }
+		b = v; /* a^256 */
+		v = 1;
+		for (i = 0; i < 120; i++) { t->hi[r][i] = (uint16_t)v; v = v * b % m[r]; }
+	}
+}
+
+ISG_HD void isg_wh_step(isg_wh *s)
+{
+	s->s1 = (ISG_A1 * s->s1) % ISG_M1;
+	s->s2 = (ISG_A2 * s->s2) % ISG_M2;
+	s->s3 = (ISG_A3 * s->s3) % ISG_M3;
+}
+
+/* the uniform belonging to the CURRENT state (call after isg_wh_step) */
+ISG_HD double isg_wh_value(const isg_wh *s)
+{
+	double x = (double)s->s1 / 30269.0 + (double)s->s2 / 30307.0 + (double)s->s3 / 30323.0;
+	/* fmod(x, 1.0) for 0 <= x < 3: both subtractions are exact */
+	if (x >= 2.0) x -= 2.0;
+	else if (x >= 1.0) x -= 1.0;
+	return x;
+}
+
+ISG_HD double isg_wh_next(isg_wh *s)
+{
+	isg_wh_step(s);
+	return isg_wh_value(s);
+}
+
+/* state n draws after `s` (n = 0 returns s itself, reduced) */
+ISG_HD isg_wh isg_wh_jump(const isg_wh_tables *t, isg_wh s, uint64_t n)
+{
+	uint32_t e1 = (uint32_t)(n % (ISG_M1 - 1)), e2 = (uint32_t)(n % (ISG_M2 - 1)), e3 = (uint32_t)(n % (ISG_M3 - 1));
+	uint32_t p1 = (uint32_t)t->lo[0][e1 & 255] * t->hi[0][e1 >> 8] % ISG_M1;
+	uint32_t p2 = (uint32_t)t->lo[1][e2 & 255] * t->hi[1][e2 >> 8] % ISG_M2;
+	uint32_t p3 = (uint32_t)t->lo[2][e3 & 255] * t->hi[2][e3 >> 8] % ISG_M3;
+	isg_wh r;
+	r.s1 = (s.s1 % ISG_M1) * p1 % ISG_M1;
+	r.s2 = (s.s2 % ISG_M2) * p2 % ISG_M2;
+	r.s3 = (s.s3 % ISG_M3) * p3 % ISG_M3;
+	return r;
+}
+
+/* a stream cursor: state + number of uniforms drawn through it */
+typedef struct {
+	isg_wh s;
+	uint32_t used;
+} isg_cursor;
+
+ISG_HD double isg_cur_next(isg_cursor *c)
+{
+	c->used++;
+	return isg_wh_next(&c->s);
+}
+
+#endif
