@@ -1,6 +1,6 @@
 """Builds the native pieces in-tree (no JIT cache): the HIP library for gfx950 and the C host shim.
 
-    python -m instruct_amd.build            # libinstruct_hip.so + libinstruct_mcmc.so
+    python -m instruct_amd.build            # libinstruct_hip.so + host/mcmc_hip.o
     python -m instruct_amd.build --oracle   # also oracle/liborc.so (+ oracle/_ref when /root/reference exists)
 """
 from __future__ import annotations
@@ -15,7 +15,6 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 LIB_HIP = os.path.join(PKG, "libinstruct_hip.so")
-LIB_MCMC = os.path.join(PKG, "libinstruct_mcmc.so")
 
 
 def _newer(target, sources):
@@ -47,15 +46,15 @@ def build_hip(force=False):
 
 
 def build_host(force=False):
+    """Compiles the drop-in sampler object (plain C).  It is linked into the host program in place
+    of the reference's mcmc.o; oracle/Makefile links it against the reference
+    driver objects for the end-to-end test binary oracle/_ref/InStruct_hip."""
     src = os.path.join(HOST, "mcmc_hip.c")
-    if not os.path.exists(src):
-        return None
-    srcs = [os.path.join(HOST, f) for f in os.listdir(HOST)] + [os.path.join(ROOT, "include", "instruct_hip.h")]
-    if force or _newer(LIB_MCMC, srcs):
-        _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
-              "-o", LIB_MCMC, src, os.path.join(HOST, "nr_compat.c"),
-              "-L", PKG, "-linstruct_hip", "-Wl,-rpath,$ORIGIN", "-lm"])
-    return LIB_MCMC
+    obj = os.path.join(HOST, "mcmc_hip.o")
+    srcs = [src, os.path.join(HOST, "instruct_types.h"), os.path.join(ROOT, "include", "instruct_hip.h")]
+    if force or _newer(obj, srcs):
+        _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+    return obj
 
 
 def build_oracle():

@@ -794,3 +794,39 @@ int orc_read_text_diploid(const char *path, int *Nout, int *Lout, int **allelenu
 	*Lout = L;
 	return 0;
 }
+
+/* ------------------------------------------------------------------ isg_math.h test hooks */
+double orc_isg_log(double x) { return isg_log(x); }
+double orc_isg_exp(double x) { return isg_exp(x); }
+double orc_isg_pow(double x, double y) { return isg_pow(x, y); }
+double orc_isg_cos(double x) { return isg_cos(x); }
+double orc_isg_accsum(const double *v, long n)
+{
+	isg_acc a;
+	long i;
+	isg_acc_zero(&a);
+	for (i = 0; i < n; i++) isg_acc_add(&a, v[i]);
+	return isg_acc_value(&a);
+}
+
+/* FNV-64 of int32 / double arrays, as used in the golden files (oracle/dump_fmt.h) */
+uint64_t orc_fnv_i32(const int *v, long n)
+{
+	uint64_t h = 0xcbf29ce484222325ULL;
+	long i;
+	int b;
+	for (i = 0; i < n; i++)
+		for (b = 0; b < 4; b++) { h ^= (unsigned char)(((uint32_t)v[i]) >> (8 * b)); h *= 0x100000001b3ULL; }
+	return h;
+}
+uint64_t orc_fnv_f64(const double *v, long n)
+{
+	uint64_t h = 0xcbf29ce484222325ULL;
+	long i;
+	int b;
+	for (i = 0; i < n; i++) {
+		uint64_t u = isg_d2u(v[i]);
+		for (b = 0; b < 8; b++) { h ^= (unsigned char)(u >> (8 * b)); h *= 0x100000001b3ULL; }
+	}
+	return h;
+}

@@ -181,6 +181,22 @@ class OrcChain:
         return out
 
 
+def fnv_i32(a):
+    lib = load()
+    lib.orc_fnv_i32.restype = C.c_uint64
+    lib.orc_fnv_i32.argtypes = [C.c_void_p, C.c_long]
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return "%016x" % lib.orc_fnv_i32(_ptr(a), a.size)
+
+
+def fnv_f64(a):
+    lib = load()
+    lib.orc_fnv_f64.restype = C.c_uint64
+    lib.orc_fnv_f64.argtypes = [C.c_void_p, C.c_long]
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return "%016x" % lib.orc_fnv_f64(_ptr(a), a.size)
+
+
 def gelman_rubin(vec, numchains, totrep):
     v = np.ascontiguousarray(vec, dtype=np.float64)
     return load().orc_gelman_rubin(_ptr(v), numchains, totrep)

@@ -1,0 +1,272 @@
+"""GPU (pytest -m gpu): the HIP path, called through the C ABI, against
+  (1) the canonical oracle configuration -- bit-exact on ALL state after every sweep, both RNG schedules;
+  (2) the golden trajectories generated from the REAL reference -- bit-exact on Z, allele counts,
+      generations, qqnum and the RNG seeds after every sweep; doubles within 1e-9; final posterior
+      means (CHAIN) within the north-star tolerance 1e-6 relative;
+  (3) size-independent properties at the full benchmark size (N=10000, L=5000, K=5).
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import orc
+from instruct_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _libs():
+    orc.build()
+    capi.load()
+
+
+def _pair(geno, an, mi, K, sched, mode=2, y=1, e=1, seeds=(13, 4, 1972)):
+    h = capi.HipChain(geno, an, mi, K, mode=mode, type_freq=y, back_refl=e, rng_sched=sched)
+    o = orc.OrcChain(geno, an, mi, K, mode=mode, type_freq=y, back_refl=e, math=orc.MATH_ISG, accum=orc.ACC_EXACT, sched=sched)
+    h.setseeds(*seeds)
+    o.setseeds(*seeds)
+    initd = np.array([h.ran1() for _ in range(K)], dtype=np.float32)
+    assert np.array_equal(initd, np.array([o.ran1() for _ in range(K)], dtype=np.float32))
+    return h, o, initd
+
+
+def _same(h, o, names, where):
+    for n in names:
+        a, b = getattr(h, n)(), getattr(o, n)()
+        if isinstance(a, np.ndarray):
+            assert np.array_equal(a, np.asarray(b)), (where, n)
+        else:
+            assert a == b, (where, n, a, b)
+
+
+SWEEP_CASES = [
+    # N, L, K, missing, alleles, mode, y, e
+    (50, 100, 3, 0.0, 2, 2, 1, 1),
+    (50, 100, 3, 0.05, 3, 2, 1, 1),
+    (37, 1031, 5, 0.10, 2, 2, 1, 1),     # ragged: L not a multiple of the lane tile, heavy missing data
+    (300, 1500, 5, 0.02, 2, 2, 1, 1),
+    (64, 200, 4, 0.0, 2, 1, 1, 1),       # mode 1 (admixture only)
+    (64, 200, 4, 0.03, 4, 2, 0, 0),      # -y 0, -e 0, four alleles
+    (16, 9000, 9, 0.01, 2, 2, 1, 1),     # K > 8 kernel variant, several passes per row
+    (5, 8, 2, 0.3, 2, 2, 1, 1),          # tiny, individuals with (almost) everything missing
+]
+
+
+@pytest.mark.parametrize("sched", [capi.SCHED_REPLAY, capi.SCHED_KEYED])
+@pytest.mark.parametrize("case", SWEEP_CASES)
+def test_every_sweep_bit_exact_vs_canonical_oracle(case, sched):
+    N, L, K, miss, nall, mode, y, e = case
+    geno, an, mi = synth.code_diploid(synth.raw_alleles(N, L, K, 2, nall, miss, 7))
+    h, o, initd = _pair(geno, an, mi, K, sched, mode, y, e)
+    pos = ["seeds"] if sched == capi.SCHED_REPLAY else []
+    h.chain_init(initd)
+    o.chain_init(initd)
+    _same(h, o, ["z", "qq", "qqnum", "generation", "alpha"] + pos, "init")
+    import ctypes as C
+    o.lib.orc_iter_advance.argtypes = [C.c_void_p]
+    h.lib.isg_iter_advance.argtypes = [C.c_void_p]
+    for it in range(3):
+        h.update_P(); o.update_P()
+        _same(h, o, ["count_alleles", "freq"] + pos, (it, "P"))
+        if mode == 2:
+            h.update_S_POP(); o.update_S_POP()
+            _same(h, o, ["self_rates", "state"] + pos, (it, "S"))
+            h.update_G(); o.update_G()
+            _same(h, o, ["generation"] + pos, (it, "G"))
+        h.update_ZQ(0); o.update_ZQ(0)
+        _same(h, o, ["z", "qq", "qqnum"] + pos, (it, "ZQ"))
+        h.update_alpha(); o.update_alpha()
+        _same(h, o, ["alpha"] + pos, (it, "A"))
+        h.cal_lkh(); o.cal_lkh()
+        _same(h, o, ["indvlkh", "totallkh"], (it, "L"))
+        o.lib.orc_iter_advance(o.h)
+        h.lib.isg_iter_advance(h.h)
+    assert o.error() == 0
+    h.close()
+
+
+def _counts_hash(cnt, an):
+    K, L, A = cnt.shape
+    mask = np.arange(A)[None, :] < an[:, None]
+    return orc.fnv_i32(cnt[:, mask])
+
+
+def _runmean(m, x, step):
+    """store_chn's multiplicative running mean (mcmc.c:1327-1332), vectorised."""
+    return np.where(m != 0, m * ((step + x / np.where(m != 0, m, 1)) / (1 + step)), x / (1 + step))
+
+
+@pytest.mark.parametrize("name", sorted(gu.CASES))
+def test_replay_schedule_reproduces_reference_trajectory(name):
+    """Golden trajectories come from the reference's own sweeps (oracle/ref_dump.c)."""
+    c = gu.case_args(name)
+    geno, an, mi = gu.case_data(name)
+    lines = gu.parse(os.path.join(gu.GOLDEN, name + ".golden"))
+    hdr = gu.fields([l for l in lines if l.startswith("data ")][0])
+    assert orc.fnv_i32(geno) == hdr["hgeno"]  # same coded input as the reference reader produced
+    K, N = c["K"], geno.shape[0]
+    h = capi.HipChain(geno, an, mi, K, mode=c["mode"], type_freq=c["y"], back_refl=c["e"], rng_sched=capi.SCHED_REPLAY)
+    h.setseeds(*c["seeds"])
+    initd = np.array([[h.ran1() for _ in range(K)] for _ in range(c["c"])], dtype=np.float32)  # read_init, initial.c:56-61
+    it = iter(lines)
+    cur = next(it)
+    while not cur.startswith("init"):
+        cur = next(it)
+    while cur.startswith("initd"):
+        k = int(cur.split()[1])
+        assert gu.floats(cur) == [float(v) for v in initd[k]]
+        cur = next(it)
+    assert gu.fields(cur)["seeds"] == h.seeds()
+
+    def close(a, b, tol=1e-9):
+        a, b = np.atleast_1d(np.asarray(a, dtype=float)), np.atleast_1d(np.asarray(b, dtype=float))
+        return a.shape == b.shape and bool(np.all((a == b) | (np.abs(a - b) <= tol * np.abs(b))))
+
+    convg = []
+    for chn in range(c["c"]):
+        h.chain_init(initd[chn])
+        f = gu.fields(next(it))           # chain n init alpha= seeds=
+        assert close(h.alpha(), float.fromhex(f["alpha"]))
+        if c["mode"] == 2:
+            f = gu.fields(next(it))       # geninit
+            assert orc.fnv_i32(h.generation()) == f["hgen"]
+        f = gu.fields(next(it))           # zqinit
+        assert orc.fnv_i32(h.z()) == f["hz"] and f["seeds"] == h.seeds()
+        res, cnt_step = None, 0
+        for step in range(c["u"]):
+            h.update_P()
+            f = gu.fields(next(it))
+            assert _counts_hash(h.count_alleles(), an) == f["hcnt"] and f["seeds"] == h.seeds(), (step, "P")
+            if c["mode"] == 2:
+                h.update_S_POP()
+                line = next(it)
+                assert close(h.self_rates(), gu.floats(line)[:K]) and gu.fields(line)["seeds"] == h.seeds(), (step, "S")
+                if c["e"] == 0:
+                    assert ["st%d" % s for s in h.state()] == [t for t in line.split() if t.startswith("st")]
+                h.update_G()
+                f = gu.fields(next(it))
+                assert orc.fnv_i32(h.generation()) == f["hgen"] and f["seeds"] == h.seeds(), (step, "G")
+            h.update_ZQ(0)
+            f = gu.fields(next(it))
+            assert orc.fnv_i32(h.z()) == f["hz"] and orc.fnv_f64(h.qqnum()) == f["hqqnum"] and f["seeds"] == h.seeds(), (step, "ZQ")
+            h.update_alpha()
+            f = gu.fields(next(it))
+            assert close(h.alpha(), float.fromhex(f["alpha"])) and f["seeds"] == h.seeds(), (step, "A")
+            h.cal_lkh()
+            f = gu.fields(next(it))
+            assert close(h.totallkh(), float.fromhex(f["totallkh"])), (step, "L")
+            if c["detail"] > 0 and step % c["detail"] == 0:
+                qq, fr = h.qq(), h.freq()
+                for i in range(min(N, 4)):
+                    assert close(qq[i], gu.floats(next(it)))
+                for k in range(K):
+                    for j in range(min(geno.shape[1], 4)):
+                        assert close(fr[k, j, :an[j]], gu.floats(next(it)))
+            # CHAIN bookkeeping as the driver does it (mcmc.c:218-226)
+            if step == c["b"] - 1:
+                res = {"n": 0, "totallkh": 1.0, "qq": np.ones((N, K)), "S": np.ones(K), "gen": np.ones(N), "indv": np.ones(N)}
+            if step >= c["b"] and (step + 1 - c["b"]) % c["t"] == 0:
+                s = res["n"]
+                res["totallkh"] = float(_runmean(np.float64(res["totallkh"]), h.totallkh(), s))
+                res["qq"] = _runmean(res["qq"], h.qq(), s)
+                res["indv"] = _runmean(res["indv"], h.indvlkh(), s)
+                if c["mode"] == 2:
+                    res["S"] = _runmean(res["S"], h.self_rates(), s)
+                    res["gen"] = _runmean(res["gen"], h.generation().astype(float), s)
+                res["n"] += 1
+                if cnt_step < c["r"]:
+                    convg.append(h.totallkh())
+                cnt_step += 1
+        f = gu.fields(next(it))  # chain n done seeds=
+        assert f["seeds"] == h.seeds()
+        # posterior means: north-star tolerance 1e-6 relative (we are ~1e-12)
+        f = gu.fields(next(it))
+        assert int(f["step"]) == res["n"] and close(res["totallkh"], float.fromhex(f["totallkh"]), 1e-6)
+        assert close(res["indv"], gu.floats(next(it)), 1e-6)
+        if c["mode"] == 2:
+            assert close(res["S"], gu.floats(next(it)), 1e-6)
+            next(it)
+            assert close(res["gen"], gu.floats(next(it)), 1e-6)
+            next(it)
+        for i in range(N):
+            assert close(res["qq"][i], gu.floats(next(it))[:K], 1e-6)
+        if c["pf"] == 1:
+            next(it)
+    line = next(it)
+    assert line.startswith("convg") and close(convg, gu.floats(line))
+    if c["c"] > 1:
+        gr = gu.floats(next(it))[0]
+        assert close(capi.gelman_rubin(np.array(convg), c["c"], c["r"]), gr, 1e-6)
+    h.close()
+
+
+def test_dropin_cli_output_equals_reference_cli_output(tmp_path):
+    """The reference driver (InStruct.c, data_interface.c, result_analysis.c ... compiled from the
+    reference sources into oracle/_ref) linked with instruct_amd/host/mcmc_hip.c instead of mcmc.c
+    writes the same result file as the pure reference binary did (tests/golden/c1_cli_output.txt)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "InStruct_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
+    out = tmp_path / "out.txt"
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out), "-K", "3", "-L", "100", "-N", "50", "-p", "2",
+           "-u", "200", "-b", "100", "-t", "10", "-c", "2", "-v", "2", "-g", "1", "-r", "5", "-j", "5",
+           "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "1"]
+    log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
+
+    def body(path):
+        keep = []
+        for l in open(path, "rb").read().split(b"\n"):
+            if l.strip().startswith((b"Data File:", b"Output File:")) or b"InStruct" in l and b"-d" in l:
+                continue
+            keep.append(l)
+        return keep
+    assert body(str(out)) == body(os.path.join(gu.GOLDEN, "c1_cli_output.txt"))
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    geno, an, mi = synth.make_diploid(10000, 5000, 5)
+    return geno, an, mi
+
+
+def test_full_size_properties_config3(full_size):
+    """N=10000, L=5000, K=5 (BASELINE config 3): properties that hold at any size."""
+    geno, an, mi = full_size
+    N, L, _ = geno.shape
+    K = 5
+    hashes = {}
+    for sched in (capi.SCHED_REPLAY, capi.SCHED_KEYED):
+        for rep in range(2 if sched == capi.SCHED_KEYED else 1):
+            h = capi.HipChain(geno, an, mi, K, rng_sched=sched)
+            h.setseeds(13, 4, 1972)
+            initd = np.array([h.ran1() for _ in range(K)], dtype=np.float32)
+            h.chain_init(initd)
+            h.run(2)
+            z = h.z()
+            valid = mi == 0
+            assert (z[valid] >= 0).all() and (z[valid] < K).all() and (z[~valid] == -1).all()
+            # allele counts == bincount of (z, locus, allele) over valid copies; total = 2 * #valid loci
+            cnt = h.count_alleles()
+            idx = (z.astype(np.int64) * L + np.arange(L)[None, :, None]) * h.Amax + geno
+            ref = np.bincount(idx[np.repeat(valid[:, :, None], 2, 2)], minlength=K * L * h.Amax).reshape(K, L, h.Amax)
+            assert np.array_equal(cnt, ref) and cnt.sum() == 2 * valid.sum()
+            # qqnum rows = histogram of the individual's Z; qq rows are probability vectors
+            qn = h.qqnum()
+            zz = np.where(valid[:, :, None], z, K).reshape(N, -1)
+            assert np.array_equal(qn, np.stack([(zz == k).sum(1) for k in range(K)], 1).astype(float))
+            assert np.allclose(h.qq().sum(1), 1.0, atol=1e-12) and (h.qq() > 0).all()
+            fr = h.freq()
+            assert np.allclose(fr.sum(2), 1.0, atol=1e-12)
+            g = h.generation()
+            assert g.min() >= 1 and g.max() <= 50
+            assert np.isfinite(h.indvlkh()).all() and h.totallkh() < 0
+            hashes.setdefault(sched, []).append((orc.fnv_i32(z), orc.fnv_f64(h.qq()), orc.fnv_i32(g), h.totallkh()))
+            h.close()
+    # keyed schedule: two runs with the same seeds are identical to the last bit (order-independent sums)
+    assert hashes[capi.SCHED_KEYED][0] == hashes[capi.SCHED_KEYED][1]
