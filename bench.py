@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MCMC iterations/s of the InStruct hot path on MI355X.
+
+A "step" is one MCMC iteration of one chain = the reference loop body mcmc.c:210-215
+(update_P + update_S_POP + update_G + update_ZQ + update_alpha + cal_lkh), steady state, with the
+packed genotypes and the sampler state already resident in HBM.  Workload: BASELINE.json config 3,
+N=10000 individuals x L=5000 loci, K=5, diploid, mode 2 (-v 2 -e 1 -y 1), synthetic data.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, one chain per GPU)
+
+`value` is measured on the REPLAY schedule (stream positions identical to the reference: Z, allele
+counts, generations and seeds are bit-identical to the reference run with the same seeds).  The same
+JSON line carries the KEYED schedule (counter-based positions, all consumers concurrent) under "keyed".
+Rank 0 at N=1 also times the reference's own CPU sweeps on the host cores ("cpu_baseline").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from instruct_amd import capi, multichain, synth  # noqa: E402
+
+WORKLOADS = {
+    "c3": dict(N=10000, L=5000, K=5, name="config3: N=10000 L=5000 K=5 diploid mode 2, 1 chain per GPU"),
+    "c2": dict(N=2000, L=1000, K=5, name="config2: N=2000 L=1000 K=5 diploid mode 2, 1 chain per GPU"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+def timed_steps(chain, steps, warmup, world):
+    import torch.distributed as dist
+    chain.run(warmup)
+    lk = []
+    chain.profile_reset()
+    chain.profile(True)
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        chain.iteration()
+        lk.append(chain.totallkh())
+    sync()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    chain.profile(False)
+    if world > 1:
+        dt = multichain.max_over_ranks(dt)
+    return dt, lk, chain.profile_results()
+
+
+def roofline(prof, kernel, bytes_per_launch, traffic):
+    ms, n = prof[kernel]
+    avg_s = ms / n * 1e-3
+    gbs = bytes_per_launch / avg_s / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 6), "avg_launch_ms": round(ms / n, 4), "alg_bytes_per_launch": bytes_per_launch,
+            "traffic": traffic}
+
+
+def load_traffic():
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            return json.load(f)
+    return {}
+
+
+def cpu_baseline(geno, K, seeds):
+    """The reference's own sweeps on one host core (the reference is single threaded):
+    oracle/_ref/ref_bench = reference mcmc.c compiled from /root/reference ("reference"); if that binary
+    did not travel, the CPU restatement oracle/liborc.so in its reference configuration ("port")."""
+    N, L, _ = geno.shape
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    sample = f"chain init + 1 full iteration at N={N} L={L} K={K} (same data, same seeds); the iteration alone is timed"
+    if os.path.exists(exe):
+        with tempfile.NamedTemporaryFile(suffix=".u8", delete=False) as f:
+            np.where(geno < 0, 255, geno).astype(np.uint8).tofile(f)
+            path = f.name
+        try:
+            p = subprocess.run([exe, path, str(N), str(L), str(K), "1"] + [str(s) for s in seeds], capture_output=True, timeout=1500)
+            r = json.loads(p.stderr.decode().strip().splitlines()[-1])
+        finally:
+            os.unlink(path)
+        return {"value": round(1.0 / r["s_per_iter"], 6), "unit": "iterations/s", "cores": 1, "kind": "reference", "sample": sample,
+                "s_per_iter": r["s_per_iter"], "sweeps_s": {k: r[k] for k in ("update_P", "update_S_POP", "update_G", "update_ZQ", "update_alpha", "cal_lkh")}}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    an = np.full(L, int(geno.max()) + 1, dtype=np.int32)
+    o = orc.OrcChain(geno, an, (geno < 0).any(-1).astype(np.int32), K)
+    o.setseeds(*seeds)
+    o.chain_init(np.array([o.ran1() for _ in range(K)], dtype=np.float32))
+    t0 = time.perf_counter()
+    o.iteration()
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 6), "unit": "iterations/s", "cores": 1, "kind": "port", "sample": sample, "s_per_iter": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-keyed", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    w = WORKLOADS[args.workload]
+    K = w["K"]
+    geno, an, mi = synth.make_diploid(w["N"], w["L"], K)
+    N, L, P = geno.shape
+    seeds = multichain.rank_seeds((13, 4, 1972), rank)
+    traffic = load_traffic()
+    out = {}
+    scheds = [("replay", capi.SCHED_REPLAY)] + ([] if args.no_keyed else [("keyed", capi.SCHED_KEYED)])
+    for tag, sched in scheds:
+        ch = capi.HipChain(geno, an, mi, K, mode=2, type_freq=1, back_refl=1, rng_sched=sched, device=local)
+        ch.setseeds(*seeds)
+        ch.chain_init(np.array([ch.ran1() for _ in range(K)], dtype=np.float32))
+        dt, lk, prof = timed_steps(ch, args.steps, args.warmup, world)
+        zq = "k_zq_chain" if sched == capi.SCHED_REPLAY else "k_zq_keyed"
+        # update_ZQ launch: reads the genotype byte and writes the Z byte of every allele copy
+        rl = roofline(prof, zq, 2 * N * L * P, traffic.get(zq))
+        ckrep = min(len(lk), 20)
+        gr = None
+        if world > 1:
+            gr = multichain.gelman_rubin_all_ranks(np.array(lk[-ckrep:]))  # RCCL all-gather over xGMI
+        out[tag] = dict(value=world * args.steps / dt, ms_per_step=dt / args.steps * 1e3, roofline=rl, gelman_rubin=gr,
+                        kernels_ms={k: round(ms / n, 4) for k, (ms, n) in sorted(prof.items())},
+                        # whole iteration against the fused-design contract figure 3*N*L*P bytes
+                        iteration_frac_of_hbm=round(3 * N * L * P / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
+                        last_totallkh=lk[-1])
+        ch.close()
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu:
+            cpu = cpu_baseline(geno, K, seeds)
+        head = out["replay"]
+        line = {
+            "metric": "MCMC iterations/sec (update_P+update_ZQ+update_SG) at NxLxK", "value": round(head["value"], 4),
+            "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": w["name"], "N": N, "L": L, "K": K, "ploidy": P, "mode": 2, "rng_schedule": "replay",
+                       "chains": world, "parallelism": f"{world} independent chain(s), one per GPU"},
+            "roofline": head["roofline"], "cpu_baseline": cpu,
+            "speedup_vs_cpu": (round(head["value"] / world / cpu["value"], 2) if cpu else None),
+            "kernels_ms": head["kernels_ms"], "iteration_frac_of_hbm": head["iteration_frac_of_hbm"],
+            "gelman_rubin": head["gelman_rubin"],
+        }
+        if "keyed" in out:
+            k = out["keyed"]
+            line["keyed"] = {"value": round(k["value"], 4), "unit": "iterations/s", "ms_per_step": round(k["ms_per_step"], 4),
+                             "roofline": k["roofline"], "kernels_ms": k["kernels_ms"], "iteration_frac_of_hbm": k["iteration_frac_of_hbm"],
+                             "speedup_vs_cpu": (round(k["value"] / world / cpu["value"], 2) if cpu else None),
+                             "gelman_rubin": k["gelman_rubin"],
+                             "note": "counter-based stream positions: bit-identical to the oracle's keyed schedule, statistically equivalent to the reference"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

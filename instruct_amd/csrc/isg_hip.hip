@@ -77,6 +77,10 @@ struct ProfEntry {
 	double ms;
 	long n;
 };
+struct ProfPending {
+	const char *name;
+	hipEvent_t e0, e1;
+};
 
 struct isg_ctx {
 	isg_config cfg;
@@ -111,7 +115,9 @@ struct isg_ctx {
 	/* profiling */
 	bool prof;
 	std::vector<ProfEntry> prof_entries;
-	hipEvent_t ev0, ev1;
+	std::vector<ProfPending> prof_pending;
+	std::vector<hipEvent_t> prof_free;
+	hipEvent_t prof_cur;
 };
 
 /* ------------------------------------------------------------------------------------------ */
@@ -558,24 +564,55 @@ __global__ void k_pdirich(DevView d, isg_wh base, uint64_t pos0, uint64_t SP)
 /* host side                                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 
+/* Per-kernel timing with HIP events recorded on the launch stream.  Events come from a pool and are
+ * only resolved in prof_collect(), so enabling the profile does not add host/device syncs to the
+ * region being timed. */
+static void prof_collect(isg_ctx *c)
+{
+	for (auto &p : c->prof_pending) {
+		(void)hipEventSynchronize(p.e1);
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, p.e0, p.e1);
+		bool found = false;
+		for (auto &e : c->prof_entries)
+			if (e.name == p.name) {
+				e.ms += ms;
+				e.n++;
+				found = true;
+				break;
+			}
+		if (!found) c->prof_entries.push_back({p.name, (double)ms, 1});
+		c->prof_free.push_back(p.e0);
+		c->prof_free.push_back(p.e1);
+	}
+	c->prof_pending.clear();
+}
+static hipEvent_t prof_event(isg_ctx *c)
+{
+	if (c->prof_free.empty()) {
+		if (c->prof_pending.size() >= 2048) prof_collect(c);
+		if (c->prof_free.empty()) {
+			hipEvent_t e;
+			(void)hipEventCreate(&e);
+			return e;
+		}
+	}
+	hipEvent_t e = c->prof_free.back();
+	c->prof_free.pop_back();
+	return e;
+}
 static void prof_begin(isg_ctx *c)
 {
-	if (c->prof) (void)hipEventRecord(c->ev0, c->stream);
+	if (!c->prof) return;
+	c->prof_cur = prof_event(c);
+	(void)hipEventRecord(c->prof_cur, c->stream);
 }
 static void prof_end(isg_ctx *c, const char *name)
 {
 	if (!c->prof) return;
-	(void)hipEventRecord(c->ev1, c->stream);
-	(void)hipEventSynchronize(c->ev1);
-	float ms = 0;
-	(void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-	for (auto &e : c->prof_entries)
-		if (e.name == name) {
-			e.ms += ms;
-			e.n++;
-			return;
-		}
-	c->prof_entries.push_back({name, (double)ms, 1});
+	hipEvent_t e1 = prof_event(c);
+	(void)hipEventRecord(e1, c->stream);
+	c->prof_pending.push_back({name, c->prof_cur, e1});
 }
 
 static int check_dev_err(isg_ctx *c)
@@ -701,8 +738,6 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	c->raw_seed[0] = 13; c->raw_seed[1] = 4; c->raw_seed[2] = 1972;
 	c->raw_valid = true;
 	c->prof = false;
-	HIPCHK(hipEventCreate(&c->ev0));
-	HIPCHK(hipEventCreate(&c->ev1));
 	keyed_layout(c);
 	*out = c;
 	return 0;
@@ -717,7 +752,8 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
 	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S);
-	(void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+	prof_collect(c);
+	for (auto e : c->prof_free) (void)hipEventDestroy(e);
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -1156,7 +1192,7 @@ extern "C" int isg_get_totallkh(isg_ctx *c, double *t) { *t = c->totallkh; retur
 
 /* ---- profiling ---- */
 extern "C" int isg_profile_enable(isg_ctx *c, int on) { c->prof = on != 0; return 0; }
-extern "C" int isg_profile_count(isg_ctx *c) { return (int)c->prof_entries.size(); }
+extern "C" int isg_profile_count(isg_ctx *c) { prof_collect(c); return (int)c->prof_entries.size(); }
 extern "C" int isg_profile_get(isg_ctx *c, int idx, char *name, int cap, double *ms, long *n)
 {
 	if (idx < 0 || idx >= (int)c->prof_entries.size()) return fail("isg_profile_get: index out of range");
@@ -1165,7 +1201,7 @@ extern "C" int isg_profile_get(isg_ctx *c, int idx, char *name, int cap, double 
 	*n = c->prof_entries[idx].n;
 	return 0;
 }
-extern "C" int isg_profile_reset(isg_ctx *c) { c->prof_entries.clear(); return 0; }
+extern "C" int isg_profile_reset(isg_ctx *c) { prof_collect(c); c->prof_entries.clear(); return 0; }
 
 /* ---- Gelman-Rubin on the gathered log-likelihood samples (check_converg.c:100-153) ---- */
 extern "C" double isg_gelman_rubin(const double *vec, int numchains, int totrep)
