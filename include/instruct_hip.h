@@ -122,6 +122,10 @@ int isg_profile_count(isg_ctx *ctx);
 int isg_profile_get(isg_ctx *ctx, int idx, char *name, int name_cap, double *total_ms, long *launches);
 int isg_profile_reset(isg_ctx *ctx);
 
+/* host-only exhaustive check of the device's integer/float shortcuts (LCG step without division,
+ * quotient by reciprocal + fma, table skip-ahead) against the plain formulas of random.c:19-47 */
+int isg_selftest(void);
+
 /* one-shot exchange of the per-chain log-likelihood samples for the Gelman-Rubin check
  * (CONVG.convg_ld, mcmc.c:223-224; check_converg.c:100-153): see instruct_amd/host */
 double isg_gelman_rubin(const double *vec, int numchains, int totrep);

@@ -61,6 +61,10 @@ struct DevView {
 	const int *allelenum;
 	const int *nvalid; /* [N] loci used per individual */
 	double *freq;
+	float *freqf;        /* single precision copy of freq, [L][Amax][KPF]: pre-filter of the Z draws */
+	int KPF;
+	const double *tape;  /* replay schedule: the uniforms of the ZQ phase in stream order */
+	unsigned long long tape_len;
 	int *cnt;
 	double *qq;
 	int *qqnum;
@@ -112,6 +116,8 @@ struct isg_ctx {
 	uint64_t *d_pos;
 	unsigned *d_err;
 	double *d_S;
+	double *d_tape;
+	uint64_t tape_cap, nvalid_total;
 	/* profiling */
 	bool prof;
 	std::vector<ProfEntry> prof_entries;
@@ -390,152 +396,505 @@ __global__ void __launch_bounds__(BLOCK) k_loglik(DevView d)
 /* ------------------------------------------------------------------------------------------ */
 /* k_zq: update_ZQ (mcmc.c:1122-1203)                                                          */
 /* ------------------------------------------------------------------------------------------ */
+/*
+ * disc_unif (random.c:403-430) without the K divisions.  The reference divides the running sums by
+ * the last one and returns the bucket i with v[i-1] < x <= v[i]; as the v[i] are non-decreasing that
+ * bucket is  #{ m <= K-2 : fl(cum[m]/tot) < x }.  The sign of d = fma(x, tot, -cum[m]) decides the
+ * comparison whenever |d| exceeds a 2^-48 relative guard band; inside the band (probability ~1e-14
+ * per draw) the exact division is evaluated, so the result is always the reference's.
+ */
+template <int KMAX>
+__device__ __forceinline__ int bucket_fast(double x, const double (&cum)[KMAX], double tot, int K)
+{
+	const double thr = (x * tot) * 0x1p-48;
+	bool amb = !(tot > 1e-280 && tot < 1e280);
+	int z = 0;
+#pragma unroll
+	for (int m = 0; m < KMAX - 1; m++) {
+		if (m < K - 1) {
+			double dd = isg_fma(x, tot, -cum[m]);
+			z += (dd > thr) ? 1 : 0;
+			amb |= !(dd > thr || dd < -thr);
+		}
+	}
+	if (amb) {
+		z = 0;
+#pragma unroll
+		for (int m = 0; m < KMAX - 1; m++)
+			if (m < K - 1) z += (cum[m] / tot < x) ? 1 : 0;
+	}
+	return z;
+}
+
+/* branch-free core of bucket_fast: bucket from the guard-banded comparisons, *amb set when any
+ * comparison fell inside the band (the caller then re-evaluates that draw with exact divisions) */
+template <int KMAX>
+__device__ __forceinline__ int bucket_core(double x, const double (&cum)[KMAX], double tot, int K, bool *amb)
+{
+	const double p = x * tot, thr = p * 0x1p-48;
+	bool a = !(tot > 1e-280 && tot < 1e280);
+	int z = 0;
+#pragma unroll
+	for (int m = 0; m < KMAX - 1; m++) {
+		if (m < K - 1) {
+			const double dd = isg_fma(x, tot, -cum[m]);
+			z += (dd > thr) ? 1 : 0;
+			a |= !(dd > thr || dd < -thr);
+		}
+	}
+	*amb = a;
+	return z;
+}
+template <int KMAX>
+__device__ __forceinline__ int bucket_exact(double x, const double (&cum)[KMAX], double tot, int K)
+{
+	int z = 0;
+#pragma unroll
+	for (int m = 0; m < KMAX - 1; m++)
+		if (m < K - 1) z += (cum[m] / tot < x) ? 1 : 0;
+	return z;
+}
+
+/* running sums cum[m] = sum_{m' <= m} qq[m'] * freq[m'][j][a] in the reference's order (mcmc.c:1146-1147) */
+template <int KMAX>
+__device__ __forceinline__ double weights(const double *__restrict__ F, const double (&q)[KMAX], double (&cum)[KMAX], int K)
+{
+	double run = 0;
+#pragma unroll
+	for (int m = 0; m < KMAX; m += 2) {
+		if (m < K) {
+			const double2 f = *(const double2 *)(F + m); /* rows are KP = even(K) doubles, 16 B aligned */
+			double w = q[m] * f.x;
+			run = (m == 0) ? w : run + w;
+			cum[m] = run;
+			if (m + 1 < K) {
+				run = run + q[m + 1] * f.y;
+				cum[m + 1] = run;
+			}
+		}
+	}
+	return run;
+}
+
+#ifdef ISG_STAMPS
+__device__ unsigned long long g_stamps[4096 * 8];
+#define STAMP(i, k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && (i) < 4096) g_stamps[(i) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int isg_diag_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 4096 * 8); }
+#else
+#define STAMP(i, k) do { } while (0)
+#endif
+
+/* workgroup barrier for hand-offs that go through LDS only: waits for this wave's LDS traffic, not for
+ * its outstanding global stores (Z bytes, qq rows) -- nobody in the workgroup reads those back */
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+/* same running sums from frequency rows already in registers */
+template <int KMAX>
+__device__ __forceinline__ double weights_reg(const double (&F)[KMAX], const double (&q)[KMAX], double (&cum)[KMAX], int K)
+{
+	double run = 0;
+#pragma unroll
+	for (int m = 0; m < KMAX; m++) {
+		if (m < K) {
+			double w = q[m] * F[m];
+			run = (m == 0) ? w : run + w;
+		}
+		cum[m] = run;
+	}
+	return run;
+}
+
+struct ZqShared {
+	isg_wh_tables tab;          /* skip-ahead tables (2.2 KB) */
+	unsigned scan[17];
+	int hist[2][ISG_KCAP];      /* bucket counts, double buffered by individual parity (chain kernel) */
+	double at_val[1024];        /* Dirichlet attempt table: value (< 0: rejected) ... */
+	unsigned char at_used[1024];/* ... and uniforms consumed, per (gamma m, even start offset) */
+	double gval[ISG_KCAP];      /* accepted gamma values, stream order */
+	unsigned long long used_total;
+};
+
+/*
+ * rdirich(qqnum[i], K, &qq[i], alpha) (mcmc.c:1196-1198, random.c:264-280).  The K gammas consume the
+ * stream one after the other and every rejected attempt restarts at the position the previous one
+ * stopped at (random.c:233-250); an attempt's outcome depends only on (shape, start position).  So
+ * all (gamma m, even offset) attempts are evaluated concurrently into a table and one lane then walks
+ * the table in stream order -- same values, same consumption as the sequential loop.  Shapes equal
+ * to 1 (odd consumption, random.c:243-244) or walks that leave the table fall back to the plain loop.
+ * Returns (for every thread) the number of uniforms consumed.
+ */
 template <int BLOCK, int KMAX>
-__device__ __forceinline__ uint64_t zq_one(const DevView &d, int i, isg_wh base, uint64_t pos, int init_flag, double alpha,
-					   unsigned *sm_scan, int *sm_hist, uint64_t *sm_pos)
+__device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &sh, int i, isg_wh dstart, double alpha, int par)
 {
 	const int K = d.K, t = threadIdx.x;
-	const int nvalid = d.nvalid[i];
-	const bool fast = (nvalid == d.L);
+	int *hist = sh.hist[par];
+	int noff = BLOCK / K;
+	if (noff > 32) noff = 32;
+	if (t < K * noff) {
+		const int m = t / noff, o = t - m * noff;
+		const double a = (double)hist[m] + alpha;
+		isg_cursor c;
+		c.s = isg_wh_jump32(&sh.tab, dstart, 2u * (unsigned)o);
+		c.used = 0;
+		double r = -1;
+		if (a < 1) r = isg_rgamma1_try(&c, a);
+		else if (a > 1) r = isg_rgamma2_try(&c, a);
+		else c.used = 255; /* shape 1: exponential draw, odd consumption -> sequential fallback */
+		sh.at_val[t] = r;
+		sh.at_used[t] = (unsigned char)(c.used > 255 ? 255 : c.used);
+	}
+	lds_barrier();
+	STAMP(i, 4);
+	if (t < KMAX) sh.hist[par ^ 1][t] = 0; /* the other buffer: last read two barriers ago */
+	if (t == 0) {
+		unsigned off = 0;
+		int m = 0;
+		bool ok = true;
+		while (m < K) {
+			unsigned o = off >> 1;
+			if (o >= (unsigned)noff) { ok = false; break; }
+			double v = sh.at_val[m * noff + o];
+			unsigned u = sh.at_used[m * noff + o];
+			if (u == 255) { ok = false; break; }
+			off += u;
+			if (!(v < 0)) { sh.gval[m] = v; m++; }
+		}
+		if (!ok) { /* continue sequentially from (gamma m, offset off) */
+			isg_cursor c;
+			c.s = isg_wh_jump32(&sh.tab, dstart, off);
+			c.used = 0;
+			for (int mm = m; mm < K; mm++) sh.gval[mm] = isg_rgamma(&c, (double)hist[mm] + alpha);
+			off += c.used;
+		}
+		sh.used_total = off;
+		STAMP(i, 5);
+	}
+	lds_barrier();
+	STAMP(i, 6);
+	const unsigned used = (unsigned)sh.used_total;
+	/* the next individual only needs `used`; qq[i] = g / sum is finished off the critical path
+	 * by lanes of the last wave: hist is double buffered and gval is only rewritten three barriers later */
+	if (t >= BLOCK - 64 && t - (BLOCK - 64) < K) {
+		const int mm = t - (BLOCK - 64);
+		double sum = 0;
+		for (int k2 = 0; k2 < K; k2++) sum += sh.gval[k2];
+		d.qq[(size_t)i * K + mm] = sh.gval[mm] / sum;
+		d.qqnum[(size_t)i * K + mm] = hist[mm];
+	}
+	return used;
+}
+
+/* per-individual inputs that do not depend on the stream position: fetched one individual ahead */
+template <int KMAX>
+struct ZqPrefetch {
+	unsigned long long gb; /* this lane's first 8 genotype bytes */
+	int nvalid;
 	double q[KMAX];
+};
+template <int KMAX>
+__device__ __forceinline__ void zq_prefetch(const DevView &d, int i, int init_flag, ZqPrefetch<KMAX> &pf)
+{
+	const int t = threadIdx.x;
+	pf.gb = ~0ull;
+	if (t * ISG_LPT < d.Lp) {
+		const uint2 g = *(const uint2 *)(d.geno + (size_t)i * d.Lp * 2 + (size_t)t * ISG_LPT * 2);
+		pf.gb = ((unsigned long long)g.y << 32) | g.x;
+	}
+	pf.nvalid = d.nvalid[i];
 #pragma unroll
-	for (int m = 0; m < KMAX; m++) q[m] = (m < K && !init_flag) ? d.qq[(size_t)i * K + m] : 0.0;
-	int cnt[KMAX];
+	for (int m = 0; m < KMAX; m++) pf.q[m] = (m < d.K && !init_flag) ? d.qq[(size_t)i * d.K + m] : 0.0;
+}
+
+/*
+ * Single precision pre-filter of one Z draw.  The bucket is the number of m <= K-2 with
+ * fl(cum[m]/tot) < x (see bucket_fast).  Evaluated in float the sign of x*tot - cum[m] is right
+ * whenever it clears a guard band of 4e-6*tot (the float rounding of qq, freq, the K-term sums and x
+ * stays below 1.5e-6*tot); otherwise `amb` is raised and the caller redoes THIS draw in double
+ * (bucket_fast), so the returned Z is always the reference's.  About 3 draws in 100000 are redone.
+ */
+template <int KMAX>
+__device__ __forceinline__ int bucket_f32(float xf, const float (&F)[KMAX], const float (&qf)[KMAX], int K, bool *amb)
+{
+	float cum[KMAX], run = 0.f;
 #pragma unroll
-	for (int m = 0; m < KMAX; m++) cnt[m] = 0;
+	for (int m = 0; m < KMAX; m++) {
+		if (m < K) run = (m == 0) ? qf[m] * F[m] : run + qf[m] * F[m];
+		cum[m] = run;
+	}
+	const float p = xf * run, marg = 4e-6f * run;
+	bool a = !(run > 1e-30f && run < 1e30f);
+	int z = 0;
+#pragma unroll
+	for (int m = 0; m < KMAX - 1; m++) {
+		if (m < K - 1) {
+			const float dd = p - cum[m];
+			z += (dd > 0.f) ? 1 : 0;
+			a |= !(dd > marg || dd < -marg);
+		}
+	}
+	*amb = a;
+	return z;
+}
+
+/* Z draws of one individual; `cur` = stream state at its first position, `off` = that position counted
+ * from the start of the phase (index into the uniform tape).  Returns uniforms consumed. */
+template <int BLOCK, int KMAX, bool CHAIN>
+__device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i, isg_wh cur, unsigned long long off, int init_flag,
+					   double alpha, isg_wh mult0, isg_wh mult_pass, ZqPrefetch<KMAX> &pf)
+{
+	constexpr bool HOIST = (KMAX <= 8); /* float frequency rows of a pass in registers before they are used */
+	const int K = d.K, t = threadIdx.x;
+	STAMP(i, 0);
+	const int nvalid = pf.nvalid;
+	const bool fast = (nvalid == d.L);
+	/* the tape covers this individual's Z draws? (it always does unless the Dirichlets consumed far
+	 * more than budgeted; then the uniforms are generated on the fly) */
+#ifdef ISG_ABL_NOTAPE
+	const bool taped = false;
+#else
+	const bool taped = CHAIN && d.tape != nullptr && off + 2ull * (unsigned)nvalid <= d.tape_len;
+#endif
+	double q[KMAX];
+	float qf[KMAX];
+#pragma unroll
+	for (int m = 0; m < KMAX; m++) {
+		q[m] = pf.q[m];
+		qf[m] = (float)pf.q[m];
+	}
+	unsigned long long gb = pf.gb;
+	if (CHAIN && i + 1 < d.N) zq_prefetch<KMAX>(d, i + 1, init_flag, pf); /* lands while this individual is processed */
+	double icum[KMAX];
+	if (init_flag) {
+#pragma unroll
+		for (int m = 0; m < KMAX; m++) icum[m] = (m < K) ? (double)(m + 1) / K : 0.0; /* mcmc.c:1144 */
+	}
+	/* per-wave bucket counts: ballots + scalar popcounts, no cross-lane data movement */
+	int wcnt[KMAX];
+#pragma unroll
+	for (int m = 0; m < KMAX; m++) wcnt[m] = 0;
+	const int par = CHAIN ? (i & 1) : 0;
 	const size_t rowb = (size_t)d.Lp * 2;
 	const uint8_t *grow = d.geno + (size_t)i * rowb;
 	uint8_t *zrow = d.z + (size_t)i * rowb;
-	unsigned running = 0; /* valid loci before this pass */
+	unsigned running = 0;
+	isg_wh mult = mult0;
 	for (int jb = 0; jb < d.Lp; jb += BLOCK * ISG_LPT) {
 		const int j0 = jb + t * ISG_LPT;
-		unsigned long long gb = ~0ull;
-		if (j0 < d.Lp) {
-			const uint2 g = *(const uint2 *)(grow + (size_t)j0 * 2);
-			gb = ((unsigned long long)g.y << 32) | g.x;
+		unsigned long long gnext = ~0ull;
+		if (j0 + BLOCK * ISG_LPT < d.Lp) {
+			const uint2 g = *(const uint2 *)(grow + (size_t)(j0 + BLOCK * ISG_LPT) * 2);
+			gnext = ((unsigned long long)g.y << 32) | g.x;
 		}
-		unsigned nv = 0;
+		/* phase 1: single precision frequency rows of the (up to) 8 allele copies */
+		float R0[HOIST ? ISG_LPT : 1][KMAX], R1[HOIST ? ISG_LPT : 1][KMAX];
+		if (HOIST && !init_flag) {
 #pragma unroll
-		for (int l = 0; l < ISG_LPT; l++) nv += (((unsigned)(gb >> (16 * l)) & 0xff) != 0xff) ? 1u : 0u;
-		unsigned rank_loci;
-		if (fast) {
-			rank_loci = (unsigned)j0;
-		} else {
-			unsigned tot;
-			rank_loci = running + block_excl_scan<BLOCK>(nv, sm_scan, &tot);
-			running += tot;
-		}
-		if (j0 < d.Lp) {
-			unsigned long long zb = ~0ull;
-			if (nv) {
-				isg_wh s = isg_wh_jump(d.tab, base, pos + 2ull * rank_loci);
+			for (int l = 0; l < ISG_LPT; l++) {
+				unsigned a0 = (unsigned)(gb >> (16 * l)) & 0xff, a1 = (unsigned)(gb >> (16 * l + 8)) & 0xff;
+				const int j = (j0 + l < d.L) ? j0 + l : 0;
+				if (a0 == 0xff) { a0 = 0; a1 = 0; }
+#ifdef ISG_ABL_NOROWS
+				const float *F0 = d.freqf + (size_t)(a0 & 1) * d.KPF, *F1 = d.freqf + (size_t)(a1 & 1) * d.KPF;
+#else
+				const float *F0 = d.freqf + ((size_t)j * d.Amax + a0) * d.KPF, *F1 = d.freqf + ((size_t)j * d.Amax + a1) * d.KPF;
+#endif
 #pragma unroll
-				for (int l = 0; l < ISG_LPT; l++) {
-					unsigned a0 = (unsigned)(gb >> (16 * l)) & 0xff;
-					if (a0 == 0xff) continue;
-#pragma unroll
-					for (int cp = 0; cp < 2; cp++) {
-						unsigned a = (unsigned)(gb >> (16 * l + 8 * cp)) & 0xff;
-						double x = isg_wh_next(&s);
-						double cum[KMAX];
-						if (init_flag) {
-#pragma unroll
-							for (int m = 0; m < KMAX; m++) cum[m] = (m < K) ? (double)(m + 1) / K : 0.0;
-						} else {
-							const double *F = d.freq + ((size_t)(j0 + l) * d.Amax + a) * d.KP;
-							double run = 0;
-#pragma unroll
-							for (int m = 0; m < KMAX; m++) {
-								if (m < K) {
-									double w = q[m] * F[m];
-									run = (m == 0) ? w : run + w;
-								}
-								cum[m] = run;
-							}
-						}
-						/* disc_unif (random.c:403-430) on cum[0..K-1] */
-						double tot = cum[0];
-#pragma unroll
-						for (int m = 1; m < KMAX; m++) if (m == K - 1) tot = cum[m];
-						double prev = cum[0] / tot;
-						int zsel = 0;
-						if (!(x <= prev && x >= 0.0)) {
-#pragma unroll
-							for (int m = 1; m < KMAX; m++) {
-								if (m < K) {
-									double cur = cum[m] / tot;
-									if (x > prev && x <= cur) zsel = m;
-									prev = cur;
-								}
-							}
-						}
-#pragma unroll
-						for (int m = 0; m < KMAX; m++) cnt[m] += (zsel == m) ? 1 : 0;
-						zb = (zb & ~(0xffull << (16 * l + 8 * cp))) | ((unsigned long long)zsel << (16 * l + 8 * cp));
+				for (int m = 0; m < KMAX; m += 4) {
+					if (m < K) {
+						const float4 f0 = *(const float4 *)(F0 + m), f1 = *(const float4 *)(F1 + m);
+						R0[l][m] = f0.x; R1[l][m] = f1.x;
+						if (m + 1 < KMAX) { R0[l][m + 1] = f0.y; R1[l][m + 1] = f1.y; }
+						if (m + 2 < KMAX) { R0[l][m + 2] = f0.z; R1[l][m + 2] = f1.z; }
+						if (m + 3 < KMAX) { R0[l][m + 3] = f0.w; R1[l][m + 3] = f1.w; }
 					}
 				}
 			}
+		}
+		/* phase 2: the lane's uniforms (one per allele copy of its used loci, in stream order) */
+		unsigned nv = 0;
+#pragma unroll
+		for (int l = 0; l < ISG_LPT; l++) nv += (((unsigned)(gb >> (16 * l)) & 0xff) != 0xff) ? 1u : 0u;
+		unsigned rank; /* used loci of this individual before the lane's first locus */
+		if (fast) {
+			rank = (unsigned)j0;
+		} else {
+			unsigned tot;
+			rank = running + block_excl_scan<BLOCK>(nv, sh.scan, &tot);
+			running += tot;
+		}
+		double x[2 * ISG_LPT];
+		if (taped) {
+			const double *tp = d.tape + off + 2ull * rank;
+			unsigned k = 0;
+#pragma unroll
+			for (int l = 0; l < ISG_LPT; l++) {
+				const bool valid = (((unsigned)(gb >> (16 * l)) & 0xff) != 0xff);
+				x[2 * l] = valid ? tp[k] : 0.0;
+				x[2 * l + 1] = valid ? tp[k + 1] : 0.0;
+				k += valid ? 2u : 0u;
+			}
+		} else {
+			isg_wh s;
+			if (fast) {
+				s = isg_wh_mul(cur, mult);
+				mult = isg_wh_mul(mult, mult_pass);
+			} else {
+				s = isg_wh_jump32(&sh.tab, cur, 2u * rank);
+			}
+#pragma unroll
+			for (int l = 0; l < ISG_LPT; l++) {
+				const bool valid = (((unsigned)(gb >> (16 * l)) & 0xff) != 0xff);
+				isg_wh s2 = s;
+				x[2 * l] = isg_wh_next(&s2);
+				x[2 * l + 1] = isg_wh_next(&s2);
+				s.s1 = valid ? s2.s1 : s.s1; /* unused loci consume nothing (mcmc.c:1137) */
+				s.s2 = valid ? s2.s2 : s.s2;
+				s.s3 = valid ? s2.s3 : s.s3;
+			}
+		}
+		/* phase 3: buckets.  Straight-line float pre-filter over the 8 copies; flagged draws are redone
+		 * in double afterwards (rare), so no data-dependent branch sits between the dependency chains. */
+		int zz[2 * ISG_LPT];
+		unsigned redo = 0;
+		if (init_flag) {
+#pragma unroll
+			for (int c8 = 0; c8 < 2 * ISG_LPT; c8++) zz[c8] = bucket_fast<KMAX>(x[c8], icum, 1.0, K); /* vec[K-1] = K/K */
+		} else if (HOIST) {
+#pragma unroll
+			for (int l = 0; l < ISG_LPT; l++) {
+#ifdef ISG_ABL_NOBUCKET
+				zz[2 * l] = (x[2 * l] > 0.5) ? 1 : 0;
+				zz[2 * l + 1] = (x[2 * l + 1] > 0.5) ? 1 : 0;
+				if (R0[l][0] + R1[l][0] + qf[0] == 123.f) redo = 1;
+#else
+				bool amb;
+				zz[2 * l] = bucket_f32<KMAX>((float)x[2 * l], R0[l], qf, K, &amb);
+				redo |= amb ? (1u << (2 * l)) : 0u;
+				zz[2 * l + 1] = bucket_f32<KMAX>((float)x[2 * l + 1], R1[l], qf, K, &amb);
+				redo |= amb ? (2u << (2 * l)) : 0u;
+#endif
+			}
+		} else {
+			redo = 0xffu;
+		}
+		if (redo) {
+#pragma unroll
+			for (int l = 0; l < ISG_LPT; l++) {
+				const unsigned a0 = (unsigned)(gb >> (16 * l)) & 0xff, a1 = (unsigned)(gb >> (16 * l + 8)) & 0xff;
+				if (a0 == 0xff) continue;
+				double cum[KMAX], tot;
+				if (redo & (1u << (2 * l))) {
+					tot = weights<KMAX>(d.freq + ((size_t)(j0 + l) * d.Amax + a0) * d.KP, q, cum, K);
+					zz[2 * l] = bucket_fast<KMAX>(x[2 * l], cum, tot, K);
+				}
+				if (redo & (2u << (2 * l))) {
+					tot = weights<KMAX>(d.freq + ((size_t)(j0 + l) * d.Amax + a1) * d.KP, q, cum, K);
+					zz[2 * l + 1] = bucket_fast<KMAX>(x[2 * l + 1], cum, tot, K);
+				}
+			}
+		}
+		unsigned long long zb = ~0ull;
+#pragma unroll
+		for (int l = 0; l < ISG_LPT; l++) {
+			const bool valid = (((unsigned)(gb >> (16 * l)) & 0xff) != 0xff);
+			const int z0 = valid ? zz[2 * l] : 0xff, z1 = valid ? zz[2 * l + 1] : 0xff; /* 0xff: locus unused */
+#ifndef ISG_ABL_NOBALLOT
+#pragma unroll
+			for (int m = 0; m < KMAX; m++)
+				if (m < K) wcnt[m] += __popcll(__ballot(z0 == m)) + __popcll(__ballot(z1 == m));
+#else
+			wcnt[0] += z0 + z1;
+#endif
+			zb = (zb & ~(0xffffull << (16 * l))) | ((unsigned long long)(z0 | (z1 << 8)) << (16 * l));
+		}
+#ifndef ISG_ABL_NOSTORE
+		if (j0 < d.Lp) {
 			uint2 zo;
 			zo.x = (unsigned)zb;
 			zo.y = (unsigned)(zb >> 32);
 			*(uint2 *)(zrow + (size_t)j0 * 2) = zo;
 		}
+#else
+		if (zb == 0x1234567ull) d.err[0] = 1; /* keep zb alive */
+#endif
+		gb = gnext;
 	}
-	/* qqnum[i][m] (mcmc.c:1176-1194): wave reduce, then LDS */
-	__syncthreads();
-	if (t < KMAX) sm_hist[t] = 0;
-	__syncthreads();
+	STAMP(i, 1);
+	/* qqnum[i][m] (mcmc.c:1176-1194): one LDS add per wave and cluster into the (pre-zeroed) buffer */
+	STAMP(i, 2);
+	if (lane_id() == 0) {
 #pragma unroll
-	for (int m = 0; m < KMAX; m++) {
-		if (m < K) {
-			int v = cnt[m];
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-			if (lane_id() == 0 && v) atomicAdd(&sm_hist[m], v);
-		}
+		for (int m = 0; m < KMAX; m++)
+			if (m < K && wcnt[m]) atomicAdd(&sh.hist[par][m], wcnt[m]);
 	}
-	__syncthreads();
-	if (t == 0) {
-		/* rdirich(qqnum[i], K, &qq[i], alpha) (mcmc.c:1196-1198) */
-		isg_cursor c;
-		c.s = isg_wh_jump(d.tab, base, pos + 2ull * (unsigned)nvalid);
-		c.used = 0;
-		double g[KMAX], sum = 0;
-#pragma unroll
-		for (int m = 0; m < KMAX; m++) {
-			if (m < K) {
-				g[m] = isg_rgamma(&c, (double)sm_hist[m] + alpha);
-				sum += g[m];
-			}
-		}
-#pragma unroll
-		for (int m = 0; m < KMAX; m++) {
-			if (m < K) {
-				d.qq[(size_t)i * K + m] = g[m] / sum;
-				d.qqnum[(size_t)i * K + m] = sm_hist[m];
-			}
-		}
-		*sm_pos = pos + 2ull * (unsigned)nvalid + c.used;
-	}
-	__syncthreads();
-	return *sm_pos;
+	lds_barrier();
+	STAMP(i, 3);
+	const isg_wh dstart = isg_wh_jump32(&sh.tab, cur, 2u * (unsigned)nvalid);
+	return 2u * (unsigned)nvalid + dirichlet_block<BLOCK, KMAX>(d, sh, i, dstart, alpha, par);
 }
 
 template <int BLOCK, int KMAX, bool CHAIN>
 __global__ void __launch_bounds__(BLOCK) k_zq(DevView d, isg_wh base, uint64_t pos0, uint64_t stride, int init_flag, double alpha,
 					      uint64_t *pos_out)
 {
-	__shared__ unsigned sm_scan[BLOCK / 64 + 1];
-	__shared__ int sm_hist[KMAX];
-	__shared__ uint64_t sm_pos;
-	if (CHAIN) {
-		uint64_t pos = pos0;
-		for (int i = 0; i < d.N; i++) pos = zq_one<BLOCK, KMAX>(d, i, base, pos, init_flag, alpha, sm_scan, sm_hist, &sm_pos);
-		if (threadIdx.x == 0) *pos_out = pos;
-	} else {
-		int i = blockIdx.x;
-		zq_one<BLOCK, KMAX>(d, i, base, pos0 + (uint64_t)i * stride, init_flag, alpha, sm_scan, sm_hist, &sm_pos);
+	__shared__ ZqShared sh;
+	const int t = threadIdx.x;
+	{ /* skip-ahead tables -> LDS */
+		const uint16_t *src = (const uint16_t *)d.tab;
+		uint16_t *dst = (uint16_t *)&sh.tab;
+		for (int k = t; k < (int)(sizeof(isg_wh_tables) / 2); k += BLOCK) dst[k] = src[k];
+		if (t < 2 * ISG_KCAP) (&sh.hist[0][0])[t] = 0;
 	}
+	__syncthreads();
+	/* multipliers for lane t: its first copy sits 2*4*t uniforms into a pass, a pass spans 8*BLOCK */
+	const isg_wh mult0 = isg_wh_power(&sh.tab, 8u * (unsigned)t);
+	const isg_wh mult_pass = isg_wh_power(&sh.tab, 8u * (unsigned)BLOCK);
+	ZqPrefetch<KMAX> pf;
+	if (CHAIN) {
+		isg_wh cur = isg_wh_jump(&sh.tab, base, pos0);
+		uint64_t total = 0;
+		zq_prefetch<KMAX>(d, 0, init_flag, pf);
+		for (int i = 0; i < d.N; i++) {
+			unsigned used = zq_one<BLOCK, KMAX, true>(d, sh, i, cur, total, init_flag, alpha, mult0, mult_pass, pf);
+			cur = isg_wh_jump32(&sh.tab, cur, used);
+			total += used;
+		}
+		if (t == 0) *pos_out = total;
+	} else {
+		const int i = blockIdx.x;
+		isg_wh cur = isg_wh_jump(&sh.tab, base, pos0 + (uint64_t)i * stride);
+		zq_prefetch<KMAX>(d, i, init_flag, pf);
+		zq_one<BLOCK, KMAX, false>(d, sh, i, cur, 0, init_flag, alpha, mult0, mult_pass, pf);
+	}
+}
+
+/* the uniforms at positions [0, n) after `base`, in stream order (8 per lane: one skip-ahead, then stepping) */
+__global__ void __launch_bounds__(256) k_tape(const isg_wh_tables *tab, isg_wh base, unsigned long long n, double *tape)
+{
+	const unsigned long long p0 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 8ull;
+	if (p0 >= n) return;
+	isg_wh s = isg_wh_jump(tab, base, p0);
+	double v[8];
+#pragma unroll
+	for (int k = 0; k < 8; k++) v[k] = isg_wh_next(&s);
+	if (p0 + 8 <= n) {
+		double2 *o = (double2 *)(tape + p0);
+#pragma unroll
+		for (int k = 0; k < 4; k++) o[k] = make_double2(v[2 * k], v[2 * k + 1]);
+	} else {
+		for (int k = 0; k < 8 && p0 + k < n; k++) tape[p0 + k] = v[k];
+	}
+}
+
+/* single precision copy of the frequency table for the Z-draw pre-filter */
+__global__ void k_freqf(DevView d)
+{
+	const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t rows = (size_t)d.L * d.Amax;
+	if (id >= rows * d.KPF) return;
+	const size_t r = id / d.KPF;
+	const int m = (int)(id - r * d.KPF);
+	d.freqf[id] = (m < d.K) ? (float)d.freq[r * d.KP + m] : 0.f;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -625,6 +984,7 @@ static int check_dev_err(isg_ctx *c)
 	return 0;
 }
 
+static int refresh_freqf(isg_ctx *c);
 static void keyed_layout(isg_ctx *c)
 {
 	uint64_t N = c->cfg.N, L = c->cfg.L, P = c->cfg.P, K = c->cfg.K, A = c->Amax;
@@ -704,6 +1064,12 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	HIPCHK(hipMemcpy(dnv, nvalid.data(), sizeof(int) * N, hipMemcpyHostToDevice));
 	d.nvalid = dnv;
 	DALLOC(d.freq, double, (size_t)Lp * Amax * KP);
+	d.KPF = (K + 3) & ~3;
+	DALLOC(d.freqf, float, (size_t)Lp * Amax * d.KPF);
+	c->d_tape = nullptr;
+	c->tape_cap = 0;
+	c->nvalid_total = 0;
+	for (int i = 0; i < N; i++) c->nvalid_total += (uint64_t)nvalid[i];
 	DALLOC(d.cnt, int, (size_t)Lp * Amax * K);
 	DALLOC(d.qq, double, (size_t)N * K);
 	DALLOC(d.qqnum, int, (size_t)N * K);
@@ -749,7 +1115,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	(void)hipSetDevice(c->cfg.device);
 	(void)hipStreamSynchronize(c->stream);
 	DevView &d = c->d;
-	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.cnt);
+	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(c->d_tape); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
 	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S);
 	prof_collect(c);
@@ -788,6 +1154,16 @@ static int upload_freq(isg_ctx *c)
 		for (int j = 0; j < L; j++)
 			for (int a = 0; a < A; a++) c->freq_stage[((size_t)j * A + a) * KP + k] = c->freq[((size_t)k * L + j) * A + a];
 	HIPCHK(hipMemcpyAsync(c->d.freq, c->freq_stage.data(), sizeof(double) * (size_t)L * A * KP, hipMemcpyHostToDevice, c->stream));
+	return refresh_freqf(c);
+}
+static int refresh_freqf(isg_ctx *c)
+{
+	DevView &d = c->d;
+	size_t n = (size_t)d.L * d.Amax * d.KPF;
+	prof_begin(c);
+	hipLaunchKernelGGL(k_freqf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d);
+	prof_end(c, "k_freqf");
+	HIPCHK(hipGetLastError());
 	return 0;
 }
 static int download_freq(isg_ctx *c)
@@ -867,7 +1243,7 @@ extern "C" int isg_update_P(isg_ctx *c)
 		hipLaunchKernelGGL(k_pdirich, dim3((n + B - 1) / B), dim3(B), 0, c->stream, d, c->origin, iter_base(c), c->ky[KY_SP]);
 		prof_end(c, "k_pdirich");
 		HIPCHK(hipGetLastError());
-		return 0;
+		return refresh_freqf(c);
 	}
 	/* replay: the K*L Dirichlets consume the stream in (k, j) order with data-dependent length
 	 * (random.c:167-250), so they are drawn sequentially on the host from the counts */
@@ -992,7 +1368,7 @@ static void launch_zq(isg_ctx *c, bool chain, isg_wh base, uint64_t pos0, uint64
 {
 	DevView &d = c->d;
 	if (chain)
-		hipLaunchKernelGGL((k_zq<1024, KMAX, true>), dim3(1), dim3(1024), 0, c->stream, d, base, pos0, stride, init_flag, c->alpha, c->d_pos);
+		hipLaunchKernelGGL((k_zq<512, KMAX, true>), dim3(1), dim3(512), 0, c->stream, d, base, pos0, stride, init_flag, c->alpha, c->d_pos);
 	else
 		hipLaunchKernelGGL((k_zq<256, KMAX, false>), dim3(d.N), dim3(256), 0, c->stream, d, base, pos0, stride, init_flag, c->alpha, c->d_pos);
 }
@@ -1004,11 +1380,41 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 	isg_wh base = chain ? c->rng : c->origin;
 	uint64_t pos0 = chain ? 0 : (init_flag ? c->ky[KY_ZI0] : iter_base(c) + c->ky[KY_OFFZ]);
 	uint64_t stride = c->ky[KY_SZ];
+	c->d.tape = nullptr;
+	c->d.tape_len = 0;
+	if (chain) {
+		/* replay schedule: the phase consumes a contiguous run of the stream (2 uniforms per used
+		 * locus, plus each individual's Dirichlet).  Its uniforms do not depend on where the
+		 * individual boundaries fall, so they are generated up front by the whole chip; the serial
+		 * chain kernel then only reads them. */
+		uint64_t need = 2 * c->nvalid_total + 96ull * (uint64_t)c->cfg.N + 4096;
+		if (need > c->tape_cap) {
+			if (c->d_tape) HIPCHK(hipFree(c->d_tape));
+			c->d_tape = nullptr;
+			HIPCHK(hipMalloc((void **)&c->d_tape, sizeof(double) * need));
+			c->tape_cap = need;
+		}
+		prof_begin(c);
+		hipLaunchKernelGGL(k_tape, dim3((unsigned)((need + 2047) / 2048)), dim3(256), 0, c->stream, c->d.tab, base, (unsigned long long)need, c->d_tape);
+		prof_end(c, "k_tape");
+		HIPCHK(hipGetLastError());
+		c->d.tape = c->d_tape;
+		c->d.tape_len = need;
+	}
 	prof_begin(c);
-	if (K <= 4) launch_zq<4>(c, chain, base, pos0, stride, init_flag);
-	else if (K <= 8) launch_zq<8>(c, chain, base, pos0, stride, init_flag);
-	else if (K <= 16) launch_zq<16>(c, chain, base, pos0, stride, init_flag);
-	else launch_zq<32>(c, chain, base, pos0, stride, init_flag);
+	switch (K) { /* small K: exact-size register arrays; larger K: rounded up */
+	case 1: case 2: launch_zq<2>(c, chain, base, pos0, stride, init_flag); break;
+	case 3: launch_zq<3>(c, chain, base, pos0, stride, init_flag); break;
+	case 4: launch_zq<4>(c, chain, base, pos0, stride, init_flag); break;
+	case 5: launch_zq<5>(c, chain, base, pos0, stride, init_flag); break;
+	case 6: launch_zq<6>(c, chain, base, pos0, stride, init_flag); break;
+	case 7: case 8: launch_zq<8>(c, chain, base, pos0, stride, init_flag); break;
+	default:
+		if (K <= 12) launch_zq<12>(c, chain, base, pos0, stride, init_flag);
+		else if (K <= 16) launch_zq<16>(c, chain, base, pos0, stride, init_flag);
+		else if (K <= 24) launch_zq<24>(c, chain, base, pos0, stride, init_flag);
+		else launch_zq<32>(c, chain, base, pos0, stride, init_flag);
+	}
 	prof_end(c, chain ? "k_zq_chain" : "k_zq_keyed");
 	HIPCHK(hipGetLastError());
 	if (chain) {
@@ -1202,6 +1608,33 @@ extern "C" int isg_profile_get(isg_ctx *c, int idx, char *name, int cap, double 
 	return 0;
 }
 extern "C" int isg_profile_reset(isg_ctx *c) { prof_collect(c); c->prof_entries.clear(); return 0; }
+
+/* ---- host-side self test of the integer/float shortcuts used on the device (no GPU needed) ---- */
+extern "C" int isg_selftest(void)
+{
+	static const uint32_t M[3] = {ISG_M1, ISG_M2, ISG_M3}, A[3] = {ISG_A1, ISG_A2, ISG_A3};
+	static const double MD[3] = {30269.0, 30307.0, 30323.0};
+	for (int g = 0; g < 3; g++) {
+		volatile float inv = 1.0f / (float)M[g];
+		volatile double md = MD[g];
+		const double invd = 1.0 / md;
+		for (uint32_t s = 0; s < M[g] + 2000; s++) {
+			if (isg_lcg_fast(s, A[g], M[g], inv) != (A[g] * s) % M[g]) return fail("isg_selftest: isg_lcg_fast differs from (a*s) % m");
+			if (isg_wh_div(s, md, invd) != (double)s / md) return fail("isg_selftest: isg_wh_div differs from s / m");
+		}
+	}
+	isg_wh_tables tab;
+	isg_wh_tables_init(&tab);
+	isg_wh s0 = {13, 4, 1972}, s = s0;
+	for (uint64_t n = 1; n <= 70000; n++) {
+		isg_wh_step(&s);
+		if (n % 997 == 0 || n < 600) {
+			isg_wh j = isg_wh_jump(&tab, s0, n), j32 = isg_wh_jump32(&tab, s0, (uint32_t)n);
+			if (j.s1 != s.s1 || j.s2 != s.s2 || j.s3 != s.s3 || j32.s1 != s.s1 || j32.s2 != s.s2 || j32.s3 != s.s3) return fail("isg_selftest: skip-ahead differs from stepping");
+		}
+	}
+	return 0;
+}
 
 /* ---- Gelman-Rubin on the gathered log-likelihood samples (check_converg.c:100-153) ---- */
 extern "C" double isg_gelman_rubin(const double *vec, int numchains, int totrep)

@@ -46,17 +46,49 @@ static inline void isg_wh_tables_init(isg_wh_tables *t)
 	}
 }
 
+/*
+ * (a * s) mod m for s < m + 2000 (so a * s < 2^24) without integer division or 32-bit multiplies:
+ * 24-bit multiply, quotient estimate through the float reciprocal, two corrections.  Equal to
+ * (a * s) % m for every such s (exhaustive check: isg_selftest(), tests/test_wh_stream.py).
+ * 24-bit multiplies and float conversions are full-rate VALU operations on CDNA.
+ */
+ISG_HD uint32_t isg_lcg_fast(uint32_t s, uint32_t a, uint32_t m, float invm)
+{
+	uint32_t p = a * s; /* fits 24 bits: the compiler selects v_mul_u32_u24 */
+	uint32_t q = (uint32_t)((float)p * invm);
+	uint32_t r = p - q * m;
+	r = (r >= 0x80000000u) ? r + m : r;
+	r = (r >= m) ? r - m : r;
+	return r;
+}
+
 ISG_HD void isg_wh_step(isg_wh *s)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+	s->s1 = isg_lcg_fast(s->s1 & 0xffffu, ISG_A1, ISG_M1, 1.0f / 30269.0f);
+	s->s2 = isg_lcg_fast(s->s2 & 0xffffu, ISG_A2, ISG_M2, 1.0f / 30307.0f);
+	s->s3 = isg_lcg_fast(s->s3 & 0xffffu, ISG_A3, ISG_M3, 1.0f / 30323.0f);
+#else
 	s->s1 = (ISG_A1 * s->s1) % ISG_M1;
 	s->s2 = (ISG_A2 * s->s2) % ISG_M2;
 	s->s3 = (ISG_A3 * s->s3) % ISG_M3;
+#endif
 }
 
 /* the uniform belonging to the CURRENT state (call after isg_wh_step) */
+/* s / m for an integer 0 <= s < m + 70000 and m one of the three moduli: one multiply by the
+ * rounded reciprocal plus one fma-based correction step gives the correctly rounded quotient
+ * (verified exhaustively for all such s against true division: tests/test_wh_stream.py) */
+ISG_HD double isg_wh_div(uint32_t s, double m, double inv)
+{
+	double x = (double)s, q = x * inv;
+	return isg_fma(isg_fma(-q, m, x), inv, q);
+}
+
 ISG_HD double isg_wh_value(const isg_wh *s)
 {
-	double x = (double)s->s1 / 30269.0 + (double)s->s2 / 30307.0 + (double)s->s3 / 30323.0;
+	double x = isg_wh_div(s->s1, 30269.0, 1.0 / 30269.0) + isg_wh_div(s->s2, 30307.0, 1.0 / 30307.0) +
+		   isg_wh_div(s->s3, 30323.0, 1.0 / 30323.0);
 	/* fmod(x, 1.0) for 0 <= x < 3: both subtractions are exact */
 	if (x >= 2.0) x -= 2.0;
 	else if (x >= 1.0) x -= 1.0;
@@ -80,6 +112,31 @@ ISG_HD isg_wh isg_wh_jump(const isg_wh_tables *t, isg_wh s, uint64_t n)
 	r.s1 = (s.s1 % ISG_M1) * p1 % ISG_M1;
 	r.s2 = (s.s2 % ISG_M2) * p2 % ISG_M2;
 	r.s3 = (s.s3 % ISG_M3) * p3 % ISG_M3;
+	return r;
+}
+
+/* 32-bit variant for offsets inside one phase */
+ISG_HD isg_wh isg_wh_jump32(const isg_wh_tables *t, isg_wh s, uint32_t n)
+{
+	uint32_t e1 = n % (ISG_M1 - 1), e2 = n % (ISG_M2 - 1), e3 = n % (ISG_M3 - 1);
+	isg_wh r;
+	r.s1 = s.s1 % ISG_M1 * ((uint32_t)t->lo[0][e1 & 255] * t->hi[0][e1 >> 8] % ISG_M1) % ISG_M1;
+	r.s2 = s.s2 % ISG_M2 * ((uint32_t)t->lo[1][e2 & 255] * t->hi[1][e2 >> 8] % ISG_M2) % ISG_M2;
+	r.s3 = s.s3 % ISG_M3 * ((uint32_t)t->lo[2][e3 & 255] * t->hi[2][e3 >> 8] % ISG_M3) % ISG_M3;
+	return r;
+}
+/* multiplier triple a_r^n mod m_r (apply with isg_wh_mul) */
+ISG_HD isg_wh isg_wh_power(const isg_wh_tables *t, uint32_t n)
+{
+	isg_wh one = {1, 1, 1};
+	return isg_wh_jump32(t, one, n);
+}
+ISG_HD isg_wh isg_wh_mul(isg_wh s, isg_wh p)
+{
+	isg_wh r;
+	r.s1 = s.s1 * p.s1 % ISG_M1;
+	r.s2 = s.s2 * p.s2 % ISG_M2;
+	r.s3 = s.s3 * p.s3 % ISG_M3;
 	return r;
 }
 

@@ -1,0 +1,25 @@
+"""Diagnostic: per-phase cycle stamps of the replay ZQ chain kernel (ISG_STAMPS build)."""
+import os, sys, subprocess, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+diag = os.path.join(ROOT, "gpurun_out", "libdiag.so")
+extra = [a for a in sys.argv[3:] if a.startswith("-D")]
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DISG_STAMPS"] + extra + [
+                       "-o", diag, os.path.join(ROOT, "instruct_amd/csrc/isg_hip.hip")])
+from instruct_amd import capi, synth
+capi.LIB_PATH = diag
+N, L, K = int(sys.argv[1]), int(sys.argv[2]), 5
+geno, an, mi = synth.make_diploid(N, L, K)
+h = capi.HipChain(geno, an, mi, K)
+h.setseeds(13, 4, 1972)
+h.chain_init(np.array([h.ran1() for _ in range(K)], dtype=np.float32))
+h.iteration(); h.iteration()
+buf = np.zeros((4096, 8), dtype=np.uint64)
+h.lib.isg_diag_stamps(buf.ctypes.data_as(C.c_void_p))
+s = buf[100:min(N, 4000)].astype(np.int64)
+names = ["start->draws_done", "->hist_sync1", "->hist_done", "->attempts_done", "->walk_done", "->end_sync"]
+d = np.diff(s[:, :7], axis=1)
+for n, v in zip(names, d.mean(0)):
+    print(f"{n:22s} {v:9.0f} ticks")
+print("per individual (start i+1 - start i):", np.diff(s[:, 0]).mean(), "ticks; end->next start:", (s[1:, 0] - s[:-1, 6]).mean())
