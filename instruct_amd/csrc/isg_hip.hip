@@ -60,6 +60,8 @@ struct DevView {
 	uint8_t *z;
 	const int *allelenum;
 	const int *nvalid; /* [N] loci used per individual */
+	const unsigned *rankwave; /* [N][nwv]: used loci of individual i before locus 64*w */
+	int nwv;
 	double *freq;
 	float *freqf;        /* single precision copy of freq, [L][Amax][KPF]: pre-filter of the Z draws */
 	int KPF;
@@ -118,6 +120,8 @@ struct isg_ctx {
 	double *d_S;
 	double *d_tape;
 	uint64_t tape_cap, nvalid_total;
+	void *d_coop;
+	int coop; /* 1: several workgroups per individual in the replay-schedule ZQ kernel */
 	/* profiling */
 	bool prof;
 	std::vector<ProfEntry> prof_entries;
@@ -293,6 +297,7 @@ __global__ void __launch_bounds__(BLOCK) k_gprop(DevView d, const double *S, isg
 			isg_cursor c;
 			c.s = isg_wh_jump(d.tab, base, pos);
 			c.used = 0;
+			c.tape = nullptr;
 			int gen;
 			if (stat == 1) {
 				gen = isg_rgeom(&c, 1 - selfing);
@@ -484,6 +489,12 @@ extern "C" int isg_diag_stamps(unsigned long long *out) { return (int)hipMemcpyF
 #define STAMP(i, k) do { } while (0)
 #endif
 
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+	return __hiloint2double(hi, lo);
+}
+
 /* workgroup barrier for hand-offs that go through LDS only: waits for this wave's LDS traffic, not for
  * its outstanding global stores (Z bytes, qq rows) -- nobody in the workgroup reads those back */
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -524,7 +535,9 @@ struct ZqShared {
  * Returns (for every thread) the number of uniforms consumed.
  */
 template <int BLOCK, int KMAX>
-__device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &sh, int i, isg_wh dstart, double alpha, int par)
+__device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &sh, int i, isg_wh dstart, double alpha, int par,
+						   const double *dtape = nullptr, unsigned long long *pub = nullptr,
+						   unsigned long long pub_base = 0, unsigned long long pub_tag = 0)
 {
 	const int K = d.K, t = threadIdx.x;
 	int *hist = sh.hist[par];
@@ -534,8 +547,9 @@ __device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &
 		const int m = t / noff, o = t - m * noff;
 		const double a = (double)hist[m] + alpha;
 		isg_cursor c;
-		c.s = isg_wh_jump32(&sh.tab, dstart, 2u * (unsigned)o);
 		c.used = 0;
+		c.tape = dtape ? dtape + 2 * o : nullptr; /* uniforms of this stretch already on the tape */
+		if (!dtape) c.s = isg_wh_jump32(&sh.tab, dstart, 2u * (unsigned)o);
 		double r = -1;
 		if (a < 1) r = isg_rgamma1_try(&c, a);
 		else if (a > 1) r = isg_rgamma2_try(&c, a);
@@ -546,28 +560,60 @@ __device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &
 	lds_barrier();
 	STAMP(i, 4);
 	if (t < KMAX) sh.hist[par ^ 1][t] = 0; /* the other buffer: last read two barriers ago */
-	if (t == 0) {
+	if (t < 64) {
+		/* wave 0 walks the table in stream order.  With at most 256 entries every lane first takes its
+		 * (up to 4) entries into registers; a step of the walk is then a pair of v_readlane (the walk state
+		 * is wave-uniform) instead of a dependent LDS round trip. */
+		const int nent = K * noff;
+		const bool small = (nent <= 256);
+		double v4[4];
+		unsigned u4[4];
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int e = t + 64 * r;
+			v4[r] = (small && e < nent) ? sh.at_val[e] : -1.0;
+			u4[r] = (small && e < nent) ? (unsigned)sh.at_used[e] : 255u;
+		}
 		unsigned off = 0;
 		int m = 0;
 		bool ok = true;
 		while (m < K) {
-			unsigned o = off >> 1;
+			const unsigned o = off >> 1;
 			if (o >= (unsigned)noff) { ok = false; break; }
-			double v = sh.at_val[m * noff + o];
-			unsigned u = sh.at_used[m * noff + o];
+			const int e = m * noff + (int)o;
+			double v;
+			unsigned u;
+			if (small) {
+				const int r = __builtin_amdgcn_readfirstlane(e >> 6), ln = __builtin_amdgcn_readfirstlane(e & 63);
+				const double vr = (r == 0) ? v4[0] : (r == 1) ? v4[1] : (r == 2) ? v4[2] : v4[3];
+				const unsigned ur = (r == 0) ? u4[0] : (r == 1) ? u4[1] : (r == 2) ? u4[2] : u4[3];
+				v = readlane_f64(vr, ln);
+				u = (unsigned)__builtin_amdgcn_readlane((int)ur, ln);
+			} else {
+				v = sh.at_val[e];
+				u = sh.at_used[e];
+			}
 			if (u == 255) { ok = false; break; }
 			off += u;
-			if (!(v < 0)) { sh.gval[m] = v; m++; }
+			if (!(v < 0)) {
+				if (t == 0) sh.gval[m] = v;
+				m++;
+			}
 		}
-		if (!ok) { /* continue sequentially from (gamma m, offset off) */
-			isg_cursor c;
-			c.s = isg_wh_jump32(&sh.tab, dstart, off);
-			c.used = 0;
-			for (int mm = m; mm < K; mm++) sh.gval[mm] = isg_rgamma(&c, (double)hist[mm] + alpha);
-			off += c.used;
+		if (t == 0) {
+			if (!ok) { /* continue sequentially from (gamma m, offset off) */
+				isg_cursor c;
+				c.s = isg_wh_jump32(&sh.tab, dstart, off);
+				c.used = 0;
+				c.tape = nullptr;
+				for (int mm = m; mm < K; mm++) sh.gval[mm] = isg_rgamma(&c, (double)hist[mm] + alpha);
+				off += c.used;
+			}
+			sh.used_total = off;
+			/* cooperative kernel: the next individual's offset leaves as soon as it is known */
+			if (pub) __hip_atomic_store(pub, (pub_tag << 48) | (pub_base + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			STAMP(i, 5);
 		}
-		sh.used_total = off;
-		STAMP(i, 5);
 	}
 	lds_barrier();
 	STAMP(i, 6);
@@ -868,6 +914,268 @@ __global__ void __launch_bounds__(BLOCK) k_zq(DevView d, isg_wh base, uint64_t p
 	}
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* k_zq_coop: update_ZQ, replay schedule, several workgroups per individual                      */
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * In the replay schedule individual i+1 starts where individual i's Dirichlet stopped, so the
+ * individuals are processed in order; what CAN be spread out is one individual's loci.  G workgroups
+ * (one locus per lane) all work on the same individual: each draws the Z of its loci from the uniform
+ * tape at the individual's start offset, counts its buckets and hands the counts to workgroup 0, which
+ * adds them up, draws the Dirichlet and publishes the next individual's offset.
+ *
+ * Hand-offs are single naturally aligned 8-byte words that carry their own tag (16 bits derived from
+ * the individual's index), written with one agent-scope store and polled with agent-scope loads
+ * (MI355X_MICROARCH.md, "data-tagged granules"): no separate flag, no fence ordering to get wrong.
+ *   pos[slot]        = offset(48) | tag(16)                      workgroup 0 -> everyone
+ *   gran[slot][g][w] = counts 3w..3w+2 (16 bits each) | tag(16)  workgroup g -> workgroup 0
+ * Nobody runs more than one individual ahead of anybody else (the next offset needs everybody's
+ * counts), so a ring of 4 slots suffices.  Every spin is bounded and watches a common abort word.
+ */
+#define ISG_COOP_RING 4
+#define ISG_COOP_GMAX 128
+#define ISG_COOP_WMAX 11
+struct CoopBuf {
+	unsigned long long pos[ISG_COOP_RING];
+	unsigned long long gran[ISG_COOP_RING][ISG_COOP_GMAX * ISG_COOP_WMAX];
+	unsigned abort_flag;
+	unsigned overflow_flag;
+};
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v)
+{
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/* lane 0 of the calling wave polls *p until its top 16 bits equal tag; the word is returned to all lanes */
+__device__ __forceinline__ unsigned long long coop_wait(const unsigned long long *p, unsigned tag, CoopBuf *cb)
+{
+	unsigned long long v = 0;
+	if (lane_id() == 0) {
+		for (unsigned spin = 0;; spin++) {
+			v = ld_agent(p);
+			if ((unsigned)(v >> 48) == tag) break;
+			if ((spin & 1023u) == 1023u) {
+				if (__hip_atomic_load(&cb->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+				if (spin > (1u << 24)) { /* ~ seconds: somebody is stuck; release everyone */
+					__hip_atomic_store(&cb->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					break;
+				}
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+	}
+	unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+	return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int init_flag, double alpha, CoopBuf *cb, uint64_t *pos_out)
+{
+	constexpr int BLOCK = 256;
+	__shared__ ZqShared sh;
+	const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x, K = d.K;
+	const bool leader = (g == 0);
+	const int W = (K + 2) / 3;
+	{
+		const uint16_t *src = (const uint16_t *)d.tab;
+		uint16_t *dst = (uint16_t *)&sh.tab;
+		for (int k = t; k < (int)(sizeof(isg_wh_tables) / 2); k += BLOCK) dst[k] = src[k];
+		if (t < 2 * ISG_KCAP) (&sh.hist[0][0])[t] = 0;
+	}
+	__syncthreads();
+	isg_wh cur = isg_wh_jump(&sh.tab, base, 0);
+	unsigned long long off = 0; /* workgroup 0: offset of the current individual */
+	const int stride = G * BLOCK;
+	const size_t rowb = (size_t)d.Lp * 2;
+	double icum[KMAX];
+#pragma unroll
+	for (int m = 0; m < KMAX; m++) icum[m] = (m < K) ? (double)(m + 1) / K : 0.0; /* mcmc.c:1144 */
+	if (leader && t == 0) st_agent(&cb->pos[0], ((unsigned long long)1 << 48) | 0ull); /* individual 0 starts at offset 0 */
+	double touch = 0.0, touch2 = 0.0;
+	/* position independent data of the lane's upcoming locus, loaded one step ahead */
+	unsigned pa0 = 0xff, pa1 = 0xff, prw = 0;
+	float pF0[KMAX], pF1[KMAX];
+#pragma unroll
+	for (int m = 0; m < KMAX; m++) pF0[m] = pF1[m] = 0.f;
+	{
+		const int nj = g * BLOCK + t;
+		if (nj < d.Lp) {
+			const unsigned short gg = *(const unsigned short *)(d.geno + (size_t)nj * 2);
+			pa0 = gg & 0xff;
+			pa1 = gg >> 8;
+			prw = d.rankwave[nj >> 6];
+			if (pa0 != 0xff && KMAX <= 8 && !init_flag) {
+				const float *P0 = d.freqf + ((size_t)nj * d.Amax + pa0) * d.KPF, *P1 = d.freqf + ((size_t)nj * d.Amax + pa1) * d.KPF;
+#pragma unroll
+				for (int m = 0; m < KMAX; m++)
+					if (m < K) { pF0[m] = P0[m]; pF1[m] = P1[m]; }
+			}
+		}
+	}
+	int pnvalid = d.nvalid[0];
+	double pq[KMAX];
+#pragma unroll
+	for (int m = 0; m < KMAX; m++) pq[m] = (m < K && !init_flag) ? d.qq[m] : 0.0;
+	for (int i = 0; i < d.N; i++) {
+		const unsigned tag = (unsigned)(i % 65535) + 1u;
+		const int slot = i & (ISG_COOP_RING - 1), par = i & 1;
+		if (touch2 == -1.0) cb->overflow_flag = 2;
+		const int nvalid = pnvalid;
+		double q[KMAX];
+		float qf[KMAX];
+#pragma unroll
+		for (int m = 0; m < KMAX; m++) {
+			q[m] = pq[m];
+			qf[m] = (float)q[m];
+		}
+		if (i + 1 < d.N) { /* next individual's row of qq (previous iteration's values) and locus count */
+			pnvalid = d.nvalid[i + 1];
+#pragma unroll
+			for (int m = 0; m < KMAX; m++) pq[m] = (m < K && !init_flag) ? d.qq[(size_t)(i + 1) * K + m] : 0.0;
+		}
+		int wcnt[KMAX];
+#pragma unroll
+		for (int m = 0; m < KMAX; m++) wcnt[m] = 0;
+		/* the individual's start offset (the position independent loads are already in flight) */
+		STAMP(i, 0);
+		const unsigned long long pw = coop_wait(&cb->pos[slot], tag, cb);
+		STAMP(i, 1);
+		const unsigned long long offi = pw & 0xffffffffffffull;
+		const bool covered = offi + 2ull * (unsigned)nvalid + 1024ull <= d.tape_len;
+		/* cache warming loads are consumed one individual later, so nothing ever waits for them */
+		if (touch == -1.0) cb->overflow_flag = 2;
+		if (leader && covered && t < 128) touch = d.tape[offi + 2ull * (unsigned)nvalid + (unsigned)t]; /* the Dirichlet's stretch */
+		for (int j = g * BLOCK + t; j - t < d.Lp; j += stride) { /* wave-uniform trip count */
+			const unsigned a0 = pa0, a1 = pa1;
+			const bool valid = (a0 != 0xff);
+			const unsigned long long vm = __ballot(valid);
+			const unsigned rank = prw + (unsigned)__popcll(vm & ((1ull << lane_id()) - 1ull));
+			float F0[KMAX], F1[KMAX];
+#pragma unroll
+			for (int m = 0; m < KMAX; m++) { F0[m] = pF0[m]; F1[m] = pF1[m]; }
+			double x0 = 0, x1 = 0;
+			if (valid && covered) {
+				x0 = d.tape[offi + 2ull * rank];
+				x1 = d.tape[offi + 2ull * rank + 1];
+			}
+			/* position independent data of the lane's next locus: the next pass of this individual or
+			 * the first pass of the next one (then also a touch of the tape lines it will read) */
+			{
+				const bool more = (j - t + stride < d.Lp);
+				const int ni = more ? i : i + 1, nj = more ? j + stride : g * BLOCK + t;
+				pa0 = pa1 = 0xff;
+				prw = 0;
+				if (ni < d.N && nj < d.Lp) {
+					const unsigned short gg = *(const unsigned short *)(d.geno + (size_t)ni * rowb + (size_t)nj * 2);
+					pa0 = gg & 0xff;
+					pa1 = gg >> 8;
+					prw = d.rankwave[(size_t)ni * d.nwv + (nj >> 6)];
+					if (pa0 != 0xff && KMAX <= 8 && !init_flag) {
+						const float *P0 = d.freqf + ((size_t)nj * d.Amax + pa0) * d.KPF, *P1 = d.freqf + ((size_t)nj * d.Amax + pa1) * d.KPF;
+#pragma unroll
+						for (int m = 0; m < KMAX; m += 4) {
+							if (m < K) {
+								const float4 f0 = *(const float4 *)(P0 + m), f1 = *(const float4 *)(P1 + m);
+								pF0[m] = f0.x; pF1[m] = f1.x;
+								if (m + 1 < KMAX) { pF0[m + 1] = f0.y; pF1[m + 1] = f1.y; }
+								if (m + 2 < KMAX) { pF0[m + 2] = f0.z; pF1[m + 2] = f1.z; }
+								if (m + 3 < KMAX) { pF0[m + 3] = f0.w; pF1[m + 3] = f1.w; }
+							}
+						}
+					}
+					if (!more && covered) touch2 = d.tape[offi + 2ull * (unsigned)nvalid + 2ull * prw + 2u * lane_id() + 16u];
+				}
+			}
+			int z0 = 0xff, z1 = 0xff;
+			if (valid && covered) {
+				if (init_flag) {
+					z0 = bucket_fast<KMAX>(x0, icum, 1.0, K);
+					z1 = bucket_fast<KMAX>(x1, icum, 1.0, K);
+				} else {
+					bool amb0 = true, amb1 = true;
+					if (KMAX <= 8) {
+						z0 = bucket_f32<KMAX>((float)x0, F0, qf, K, &amb0);
+						z1 = bucket_f32<KMAX>((float)x1, F1, qf, K, &amb1);
+					}
+					if (amb0) {
+						double cum[KMAX];
+						double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + a0) * d.KP, q, cum, K);
+						z0 = bucket_fast<KMAX>(x0, cum, tot, K);
+					}
+					if (amb1) {
+						double cum[KMAX];
+						double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + a1) * d.KP, q, cum, K);
+						z1 = bucket_fast<KMAX>(x1, cum, tot, K);
+					}
+				}
+			}
+#pragma unroll
+			for (int m = 0; m < KMAX; m++)
+				if (m < K) wcnt[m] += __popcll(__ballot(z0 == m)) + __popcll(__ballot(z1 == m));
+			if (j < d.Lp) *(unsigned short *)(d.z + (size_t)i * rowb + (size_t)j * 2) = (unsigned short)(z0 | (z1 << 8));
+		}
+		STAMP(i, 2);
+		if (lane_id() == 0) {
+#pragma unroll
+			for (int m = 0; m < KMAX; m++)
+				if (m < K && wcnt[m]) atomicAdd(&sh.hist[par][m], wcnt[m]);
+		}
+		lds_barrier();
+		STAMP(i, 3);
+		if (!leader) {
+			if (t < KMAX) sh.hist[par ^ 1][t] = 0; /* before the hand-off in program order */
+			if (t < W) {
+				unsigned long long v = (unsigned long long)tag << 48;
+#pragma unroll
+				for (int c3 = 0; c3 < 3; c3++)
+					if (3 * t + c3 < K) v |= (unsigned long long)(sh.hist[par][3 * t + c3] & 0xffff) << (16 * c3);
+				st_agent(&cb->gran[slot][g * W + t], v);
+			}
+		} else {
+			/* gather the other workgroups' counts */
+			for (int gi = W + t; gi - t < G * W; gi += BLOCK) { /* wave-uniform trip count */
+				if (gi < G * W) {
+					unsigned long long v = 0;
+					for (unsigned spin = 0;; spin++) {
+						v = ld_agent(&cb->gran[slot][gi]);
+						if ((unsigned)(v >> 48) == tag) break;
+						if ((spin & 1023u) == 1023u) {
+							if (__hip_atomic_load(&cb->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+							if (spin > (1u << 24)) {
+								__hip_atomic_store(&cb->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+								break;
+							}
+						}
+						__builtin_amdgcn_s_sleep(1);
+					}
+					const int w = gi % W;
+#pragma unroll
+					for (int c3 = 0; c3 < 3; c3++) {
+						const int m = 3 * w + c3;
+						const int c = (int)((v >> (16 * c3)) & 0xffff);
+						if (m < K && c) atomicAdd(&sh.hist[par][m], c);
+					}
+				}
+			}
+			lds_barrier();
+			STAMP(i, 7);
+			if (!covered && t == 0) cb->overflow_flag = 1;
+			/* the generator state is only needed when the tape does not cover the Dirichlet's stretch */
+			isg_wh dstart = cur;
+			if (!covered) dstart = isg_wh_jump(&sh.tab, base, off + 2ull * (unsigned)nvalid);
+			const unsigned used = 2u * (unsigned)nvalid +
+				dirichlet_block<BLOCK, KMAX>(d, sh, i, dstart, alpha, par, covered ? d.tape + offi + 2ull * (unsigned)nvalid : nullptr,
+							     (i + 1 < d.N) ? &cb->pos[(i + 1) & (ISG_COOP_RING - 1)] : nullptr,
+							     off + 2ull * (unsigned)nvalid, (unsigned long long)((unsigned)((i + 1) % 65535) + 1u));
+			off += used;
+		}
+	}
+	if (leader && t == 0) *pos_out = off;
+}
+
 /* the uniforms at positions [0, n) after `base`, in stream order (8 per lane: one skip-ahead, then stepping) */
 __global__ void __launch_bounds__(256) k_tape(const isg_wh_tables *tab, isg_wh base, unsigned long long n, double *tape)
 {
@@ -910,6 +1218,7 @@ __global__ void k_pdirich(DevView d, isg_wh base, uint64_t pos0, uint64_t SP)
 	isg_cursor c;
 	c.s = isg_wh_jump(d.tab, base, pos0 + (uint64_t)id * SP);
 	c.used = 0;
+			c.tape = nullptr;
 	double sum = 0;
 	for (int a = 0; a < A; a++) {
 		double g = isg_rgamma(&c, (double)d.cnt[((size_t)j * d.Amax + a) * d.K + k] + 1.0);
@@ -1070,6 +1379,29 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	c->tape_cap = 0;
 	c->nvalid_total = 0;
 	for (int i = 0; i < N; i++) c->nvalid_total += (uint64_t)nvalid[i];
+	{
+		const int nwv = (Lp + 63) / 64 + 1;
+		std::vector<unsigned> rw((size_t)N * nwv, 0);
+		for (int i = 0; i < N; i++) {
+			unsigned run = 0;
+			for (int w = 0; w < nwv; w++) {
+				rw[(size_t)i * nwv + w] = run;
+				for (int j = 64 * w; j < 64 * (w + 1) && j < Lp; j++) run += (pk[((size_t)i * Lp + j) * 2] != 0xff) ? 1u : 0u;
+			}
+		}
+		unsigned *drw;
+		DALLOC(drw, unsigned, (size_t)N * nwv);
+		HIPCHK(hipMemcpy(drw, rw.data(), sizeof(unsigned) * rw.size(), hipMemcpyHostToDevice));
+		d.rankwave = drw;
+		d.nwv = nwv;
+	}
+	{
+		CoopBuf *cbp;
+		DALLOC(cbp, CoopBuf, 1);
+		c->d_coop = cbp;
+		const char *e = getenv("INSTRUCT_ZQ_COOP");
+		c->coop = (e && atoi(e) == 0) ? 0 : 1;
+	}
 	DALLOC(d.cnt, int, (size_t)Lp * Amax * K);
 	DALLOC(d.qq, double, (size_t)N * K);
 	DALLOC(d.qqnum, int, (size_t)N * K);
@@ -1115,7 +1447,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	(void)hipSetDevice(c->cfg.device);
 	(void)hipStreamSynchronize(c->stream);
 	DevView &d = c->d;
-	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(c->d_tape); (void)hipFree(d.cnt);
+	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
 	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S);
 	prof_collect(c);
@@ -1252,6 +1584,7 @@ extern "C" int isg_update_P(isg_ctx *c)
 	isg_cursor cur;
 	cur.s = c->rng;
 	cur.used = 0;
+	cur.tape = nullptr;
 	std::vector<double> tmp(A);
 	for (int k = 0; k < K; k++)
 		for (int j = 0; j < L; j++) {
@@ -1401,6 +1734,40 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 		c->d.tape = c->d_tape;
 		c->d.tape_len = need;
 	}
+	const bool coop = chain && c->coop;
+	if (coop) {
+		HIPCHK(hipMemsetAsync(c->d_coop, 0, sizeof(CoopBuf), c->stream));
+		int G = (c->d.Lp + 255) / 256;
+		if (G > ISG_COOP_GMAX) G = ISG_COOP_GMAX;
+		CoopBuf *cb = (CoopBuf *)c->d_coop;
+		prof_begin(c);
+#define COOP_LAUNCH(KM) hipLaunchKernelGGL((k_zq_coop<KM>), dim3(G), dim3(256), 0, c->stream, c->d, base, init_flag, c->alpha, cb, c->d_pos)
+		switch (K) {
+		case 1: case 2: COOP_LAUNCH(2); break;
+		case 3: COOP_LAUNCH(3); break;
+		case 4: COOP_LAUNCH(4); break;
+		case 5: COOP_LAUNCH(5); break;
+		case 6: COOP_LAUNCH(6); break;
+		case 7: case 8: COOP_LAUNCH(8); break;
+		default:
+			if (K <= 12) COOP_LAUNCH(12);
+			else if (K <= 16) COOP_LAUNCH(16);
+			else if (K <= 24) COOP_LAUNCH(24);
+			else COOP_LAUNCH(32);
+		}
+#undef COOP_LAUNCH
+		prof_end(c, "k_zq_coop");
+		HIPCHK(hipGetLastError());
+		uint64_t used = 0;
+		unsigned flags[2] = {0, 0};
+		HIPCHK(hipMemcpyAsync(&used, c->d_pos, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipMemcpyAsync(flags, &cb->abort_flag, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		if (flags[0]) return fail("isg_update_ZQ: cooperative kernel aborted (a workgroup hand-off timed out)");
+		if (flags[1]) return fail("isg_update_ZQ: uniform tape exhausted (set INSTRUCT_ZQ_COOP=0)");
+		host_advance(c, used);
+		return sync_qq_to_host(c);
+	}
 	prof_begin(c);
 	switch (K) { /* small K: exact-size register arrays; larger K: rounded up */
 	case 1: case 2: launch_zq<2>(c, chain, base, pos0, stride, init_flag); break;
@@ -1434,6 +1801,7 @@ extern "C" int isg_update_alpha(isg_ctx *c)
 	isg_cursor cur;
 	cur.s = c->rng;
 	cur.used = 0;
+	cur.tape = nullptr;
 	double ralpha = isg_rnormal(&cur, c->alpha, 1.0);
 	c->rng = cur.s;
 	c->raw_valid = false;
@@ -1501,6 +1869,7 @@ extern "C" int isg_chain_init(isg_ctx *c, const float *initd)
 		isg_cursor cur;
 		cur.s = c->rng;
 		cur.used = 0;
+	cur.tape = nullptr;
 		for (int i = 0; i < N; i++) {
 			double pr = isg_cur_next(&cur);
 			int g = isg_rgeom(&cur, pr);

@@ -140,14 +140,17 @@ ISG_HD isg_wh isg_wh_mul(isg_wh s, isg_wh p)
 	return r;
 }
 
-/* a stream cursor: state + number of uniforms drawn through it */
+/* a stream cursor: number of uniforms drawn through it + either the generator state or, when the
+ * uniforms of this stretch of the stream were generated beforehand, a pointer to them */
 typedef struct {
 	isg_wh s;
 	uint32_t used;
+	const double *tape;
 } isg_cursor;
 
 ISG_HD double isg_cur_next(isg_cursor *c)
 {
+	if (c->tape) return c->tape[c->used++];
 	c->used++;
 	return isg_wh_next(&c->s);
 }
