@@ -53,17 +53,22 @@ def timed_steps(chain, steps, warmup, world):
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        chain.iteration()
-        lk.append(chain.totallkh())
+    chain.run(steps)            # EXACTLY `steps` iterations: one C call, state stays on the device
+    last = chain.totallkh()     # drains the stream (the last cal_lkh result comes back)
     sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     chain.profile(False)
+    prof = chain.profile_results()
     if world > 1:
         dt = multichain.max_over_ranks(dt)
-    return dt, lk, chain.profile_results()
+    # log-likelihood samples for the Gelman-Rubin exchange: a few more (untimed) stored iterations
+    lk = [last]
+    for _ in range(5):
+        chain.iteration()
+        lk.append(chain.totallkh())
+    return dt, lk, prof
 
 
 def roofline(prof, kernel, bytes_per_launch, traffic):
@@ -129,11 +134,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("ISG_BENCH_BACKEND", "nccl")  # "gloo": rehearse N ranks on fewer GPUs (tests only)
+    if backend != "nccl":
+        local = local % ndev
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     w = WORKLOADS[args.workload]

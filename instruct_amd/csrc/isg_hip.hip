@@ -122,6 +122,11 @@ struct isg_ctx {
 	uint64_t tape_cap, nvalid_total;
 	void *d_coop;
 	int coop; /* 1: several workgroups per individual in the replay-schedule ZQ kernel */
+	int *d_state;
+	double *d_ratios, *d_total;
+	std::vector<double> ratios_h;
+	/* which host mirrors are current */
+	bool h_qq, h_gen, h_S, h_lkh;
 	/* profiling */
 	bool prof;
 	std::vector<ProfEntry> prof_entries;
@@ -1229,6 +1234,120 @@ __global__ void k_pdirich(DevView d, isg_wh base, uint64_t pos0, uint64_t SP)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* k_spop: update_S_POP (mcmc.c:913-983) -- one workgroup, K sequential MH steps                 */
+/* ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ double dev_q_trans(int a, int b) /* mcmc.c:1566-1593 */
+{
+	if (a == 0) return (b == 0 || b == 1) ? 0.5 : 0.0;
+	if (a == 2) return (b == 2 || b == 1) ? 0.5 : 0.0;
+	if (a == 1) return (b == 0 || b == 2) ? 0.05 : (b == 1 ? 0.90 : 0.0);
+	return 0.0;
+}
+/* proposal() (mcmc.c:1630-1648): sum over individuals of log(s_i^(g_i-1) (1-s_i)), order-independent sum */
+template <int BLOCK>
+__device__ __forceinline__ double dev_proposal(const DevView &d, const double *s, unsigned long long *smr)
+{
+	isg_acc a;
+	isg_acc_zero(&a);
+	for (int i = threadIdx.x; i < d.N; i += BLOCK) {
+		double temp = 0;
+		for (int j = 0; j < d.K; j++) temp += d.qq[(size_t)i * d.K + j] * s[j];
+		isg_acc_add(&a, isg_log(isg_pow(temp, (double)(d.gen[i] - 1)) * (1 - temp)));
+	}
+	const isg_acc r = block_reduce_acc<BLOCK>(a, smr);
+	return isg_acc_value(&r);
+}
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_spop(DevView d, double *S, int *state, isg_wh start, int back_refl, uint64_t *used_out)
+{
+	__shared__ unsigned long long smr[(BLOCK / 64) * 5];
+	__shared__ double Scur[ISG_KCAP], Stmp[ISG_KCAP];
+	__shared__ int stc[ISG_KCAP], stt[ISG_KCAP];
+	__shared__ double ld_sh;
+	const int t = threadIdx.x, K = d.K;
+	if (t < K) { Scur[t] = S[t]; stc[t] = state[t]; }
+	__syncthreads();
+	/* proposal(self_rates) only changes when a move is accepted: carried instead of recomputed */
+	double cur_ld = dev_proposal<BLOCK>(d, Scur, smr);
+	isg_cursor c;
+	c.s = start;
+	c.used = 0;
+	c.tape = nullptr;
+	for (int j = 0; j < K; j++) {
+		if (t == 0) {
+			for (int i = 0; i < K; i++) { Stmp[i] = Scur[i]; stt[i] = stc[i]; }
+			if (back_refl == 1) { /* mcmc.c:939-945 */
+				double v = isg_cur_next(&c) * 2 * 0.05 - 0.05;
+				v += Scur[j];
+				if (v <= 0.0) v = 0.0 - v;
+				else if (v >= 1.0) v = 1.0 - (v - 1.0);
+				Stmp[j] = v;
+			} else { /* adpt_indp, mcmc.c:1461-1520 */
+				const int st = stc[j];
+				double v;
+				int ns;
+				if (st == 0) {
+					if (isg_cur_next(&c) < 0.50) { v = 0.0; ns = 0; } else { v = isg_cur_next(&c); ns = 1; }
+				} else if (st == 2) {
+					if (isg_cur_next(&c) < 0.5) { v = 1.0; ns = 2; } else { v = isg_cur_next(&c); ns = 1; }
+				} else {
+					const double tt = isg_cur_next(&c);
+					if (tt <= 0.05) { v = 0.0; ns = 0; }
+					else if (tt >= 0.95) { v = 1.0; ns = 2; }
+					else { v = isg_cur_next(&c); ns = 1; }
+				}
+				Stmp[j] = v;
+				stt[j] = ns;
+			}
+		}
+		__syncthreads();
+		const double new_ld = dev_proposal<BLOCK>(d, Stmp, smr);
+		if (t == 0) {
+			double mh = isg_exp(new_ld - cur_ld);
+			if (back_refl == 0) {
+				double h = 1.0;
+				for (int i = 0; i < K; i++) h *= dev_q_trans(stc[i], stt[i]) / dev_q_trans(stt[i], stc[i]);
+				mh *= h;
+			}
+			const double thr = (1 > mh) ? mh : 1;
+			double keep = cur_ld;
+			if (isg_cur_next(&c) < thr) {
+				Scur[j] = Stmp[j];
+				if (back_refl == 0) stc[j] = stt[j];
+				keep = new_ld;
+			}
+			ld_sh = keep;
+		}
+		__syncthreads();
+		cur_ld = ld_sh;
+	}
+	if (t < K) { S[t] = Scur[t]; state[t] = stc[t]; }
+	if (t == 0) *used_out = c.used;
+}
+
+/* update_alpha: the N*K factors pow(q, ralpha + n) / pow(q, n + alpha) (mcmc.c:1258); their ORDERED
+ * product (overflow / NaN behaviour of the reference included) is formed on the host */
+__global__ void k_alpha_ratios(DevView d, double ralpha, double alpha, double *ratios)
+{
+	const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= (size_t)d.N * d.K) return;
+	const double q = d.qq[id], n = (double)d.qqnum[id];
+	ratios[id] = isg_pow(q, ralpha + n) / isg_pow(q, n + alpha);
+}
+
+/* cal_lkh: totallkh = order-independent sum of indvlkh (mcmc.c:1940) */
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_lkh_total(DevView d, double *total)
+{
+	__shared__ unsigned long long smr[(BLOCK / 64) * 5];
+	isg_acc a;
+	isg_acc_zero(&a);
+	for (int i = threadIdx.x; i < d.N; i += BLOCK) isg_acc_add(&a, d.indvlkh[i]);
+	const isg_acc r = block_reduce_acc<BLOCK>(a, smr);
+	if (threadIdx.x == 0) *total = isg_acc_value(&r);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* host side                                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -1417,6 +1536,11 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	DALLOC(c->d_pos, uint64_t, 4);
 	DALLOC(c->d_err, unsigned, 1);
 	DALLOC(c->d_S, double, ISG_KCAP);
+	DALLOC(c->d_state, int, ISG_KCAP);
+	DALLOC(c->d_ratios, double, (size_t)N * K);
+	DALLOC(c->d_total, double, 1);
+	c->ratios_h.assign((size_t)N * K, 0.0);
+	c->h_qq = c->h_gen = c->h_S = c->h_lkh = true;
 	d.err = c->d_err;
 #undef DALLOC
 	c->freq.assign((size_t)K * L * Amax, 0.0);
@@ -1449,7 +1573,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	DevView &d = c->d;
 	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
-	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S);
+	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S); (void)hipFree(c->d_state); (void)hipFree(c->d_ratios); (void)hipFree(c->d_total);
 	prof_collect(c);
 	for (auto e : c->prof_free) (void)hipEventDestroy(e);
 	(void)hipStreamDestroy(c->stream);
@@ -1508,17 +1632,40 @@ static int download_freq(isg_ctx *c)
 			for (int a = 0; a < A; a++) c->freq[((size_t)k * L + j) * A + a] = c->freq_stage[((size_t)j * A + a) * KP + k];
 	return 0;
 }
-static int sync_qq_to_host(isg_ctx *c)
+/* host mirrors are refreshed on demand only (getters, the host-side steps of the replay schedule) */
+static int ensure_qq(isg_ctx *c)
 {
+	if (c->h_qq) return 0;
 	HIPCHK(hipMemcpyAsync(c->qq.data(), c->d.qq, sizeof(double) * c->qq.size(), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(c->qqnum.data(), c->d.qqnum, sizeof(int) * c->qqnum.size(), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	c->h_qq = true;
 	return 0;
 }
-static int sync_gen_to_host(isg_ctx *c)
+static int ensure_gen(isg_ctx *c)
 {
+	if (c->h_gen) return 0;
 	HIPCHK(hipMemcpyAsync(c->gen.data(), c->d.gen, sizeof(int) * c->gen.size(), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	c->h_gen = true;
+	return 0;
+}
+static int ensure_S(isg_ctx *c)
+{
+	if (c->h_S) return 0;
+	HIPCHK(hipMemcpyAsync(c->S.data(), c->d_S, sizeof(double) * c->cfg.K, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(c->state.data(), c->d_state, sizeof(int) * c->cfg.K, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->h_S = true;
+	return 0;
+}
+static int ensure_lkh(isg_ctx *c)
+{
+	if (c->h_lkh) return 0;
+	HIPCHK(hipMemcpyAsync(c->indvlkh.data(), c->d.indvlkh, sizeof(double) * c->indvlkh.size(), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(&c->totallkh, c->d_total, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->h_lkh = true;
 	return 0;
 }
 
@@ -1598,75 +1745,25 @@ extern "C" int isg_update_P(isg_ctx *c)
 	return upload_freq(c);
 }
 
-/* ---- update_S_POP (host: O(N K) work, sequential MH over clusters) ---- */
-static double proposal(isg_ctx *c, const double *s) /* mcmc.c:1630-1648 */
-{
-	const int N = c->cfg.N, K = c->cfg.K;
-	isg_acc acc;
-	isg_acc_zero(&acc);
-	for (int i = 0; i < N; i++) {
-		double temp = 0;
-		for (int j = 0; j < K; j++) temp += c->qq[(size_t)i * K + j] * s[j];
-		isg_acc_add(&acc, isg_log(isg_pow(temp, c->gen[i] - 1) * (1 - temp)));
-	}
-	return isg_acc_value(&acc);
-}
-static double adpt_indp(isg_ctx *c, int *stat_tmp, int stat) /* mcmc.c:1461-1520 */
-{
-	double tmp = 0, tt;
-	if (stat == 0) {
-		if (host_next(c) < 0.50) { tmp = 0.0; *stat_tmp = 0; }
-		else { tmp = host_next(c); *stat_tmp = 1; }
-	} else if (stat == 2) {
-		if (host_next(c) < 0.5) { tmp = 1.0; *stat_tmp = 2; }
-		else { tmp = host_next(c); *stat_tmp = 1; }
-	} else {
-		tt = host_next(c);
-		if (tt <= 0.05) { tmp = 0.0; *stat_tmp = 0; }
-		else if (tt >= 0.95) { tmp = 1.0; *stat_tmp = 2; }
-		else { tmp = host_next(c); *stat_tmp = 1; }
-	}
-	return tmp;
-}
-static double q_trans(int a, int b) /* mcmc.c:1566-1593 */
-{
-	if (a == 0) return (b == 0 || b == 1) ? 0.5 : 0.0;
-	if (a == 2) return (b == 2 || b == 1) ? 0.5 : 0.0;
-	if (a == 1) return (b == 0 || b == 2) ? 0.05 : (b == 1 ? 0.90 : 0.0);
-	return 0.0;
-}
+/* ---- update_S_POP ---- */
 extern "C" int isg_update_S_POP(isg_ctx *c)
 {
 	if (c->cfg.mode != 2) return 0;
+	HIPCHK(hipSetDevice(c->cfg.device));
 	const int K = c->cfg.K;
-	if (is_keyed(c)) host_seek(c, iter_base(c) + c->ky[KY_OFFS]);
-	std::vector<double> tmp(K);
-	std::vector<int> tst(K);
-	/* proposal(self_rates) only changes when a move is accepted: carry it instead of recomputing */
-	double cur_ld = proposal(c, c->S.data());
-	for (int j = 0; j < K; j++) {
-		for (int i = 0; i < K; i++) { tmp[i] = c->S[i]; tst[i] = c->state[i]; }
-		if (c->cfg.back_refl == 1) {
-			tmp[j] = host_next(c) * 2 * 0.05 - 0.05;
-			tmp[j] += c->S[j];
-			if (tmp[j] <= 0.0) tmp[j] = 0.0 - tmp[j];
-			else if (tmp[j] >= 1.0) tmp[j] = 1.0 - (tmp[j] - 1.0);
-		} else {
-			tmp[j] = adpt_indp(c, &tst[j], c->state[j]);
-		}
-		double new_ld = proposal(c, tmp.data());
-		double mh = isg_exp(new_ld - cur_ld);
+	isg_wh start = is_keyed(c) ? isg_wh_jump(&c->tab_h, c->origin, iter_base(c) + c->ky[KY_OFFS]) : c->rng;
+	prof_begin(c);
+	hipLaunchKernelGGL(k_spop<1024>, dim3(1), dim3(1024), 0, c->stream, c->d, c->d_S, c->d_state, start, c->cfg.back_refl, c->d_pos + 1);
+	prof_end(c, "k_spop");
+	HIPCHK(hipGetLastError());
+	c->h_S = false;
+	if (!is_keyed(c)) {
+		uint64_t used = 2ull * (uint64_t)K; /* -e 1: one proposal + one acceptance uniform per cluster */
 		if (c->cfg.back_refl == 0) {
-			double h = 1.0;
-			for (int i = 0; i < K; i++) h *= q_trans(c->state[i], tst[i]) / q_trans(tst[i], c->state[i]);
-			mh *= h;
+			HIPCHK(hipMemcpyAsync(&used, c->d_pos + 1, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));
 		}
-		double thr = (1 > mh) ? mh : 1;
-		if (host_next(c) < thr) {
-			c->S[j] = tmp[j];
-			if (c->cfg.back_refl == 0) c->state[j] = tst[j];
-			cur_ld = new_ld;
-		}
+		host_advance(c, used);
 	}
 	return 0;
 }
@@ -1678,7 +1775,6 @@ extern "C" int isg_update_G(isg_ctx *c)
 	HIPCHK(hipSetDevice(c->cfg.device));
 	DevView &d = c->d;
 	double *d_S = c->d_S;
-	HIPCHK(hipMemcpyAsync(d_S, c->S.data(), sizeof(double) * c->cfg.K, hipMemcpyHostToDevice, c->stream));
 	isg_wh base = is_keyed(c) ? isg_wh_jump(&c->tab_h, c->origin, iter_base(c) + c->ky[KY_OFFG]) : c->rng;
 	prof_begin(c);
 	hipLaunchKernelGGL(k_gprop<1024>, dim3(1), dim3(1024), 0, c->stream, d, (const double *)d_S, base, is_keyed(c) ? 1 : 0, c->d_pos);
@@ -1687,12 +1783,14 @@ extern "C" int isg_update_G(isg_ctx *c)
 	hipLaunchKernelGGL((k_loglik<256, true>), dim3(d.N), dim3(256), 0, c->stream, d);
 	prof_end(c, "k_loglik_pair");
 	HIPCHK(hipGetLastError());
-	uint64_t used = 0;
-	HIPCHK(hipMemcpyAsync(&used, c->d_pos, sizeof(used), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(c->gen.data(), d.gen, sizeof(int) * c->gen.size(), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
-	if (!is_keyed(c)) host_advance(c, used);
-	return check_dev_err(c);
+	c->h_gen = false;
+	if (!is_keyed(c)) {
+		uint64_t used = 0;
+		HIPCHK(hipMemcpyAsync(&used, c->d_pos, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		host_advance(c, used);
+	}
+	return 0;
 }
 
 /* ---- update_ZQ ---- */
@@ -1766,7 +1864,8 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 		if (flags[0]) return fail("isg_update_ZQ: cooperative kernel aborted (a workgroup hand-off timed out)");
 		if (flags[1]) return fail("isg_update_ZQ: uniform tape exhausted (set INSTRUCT_ZQ_COOP=0)");
 		host_advance(c, used);
-		return sync_qq_to_host(c);
+		c->h_qq = false;
+		return 0;
 	}
 	prof_begin(c);
 	switch (K) { /* small K: exact-size register arrays; larger K: rounded up */
@@ -1790,13 +1889,15 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 		HIPCHK(hipStreamSynchronize(c->stream));
 		host_advance(c, used);
 	}
-	return sync_qq_to_host(c);
+	c->h_qq = false;
+	return 0;
 }
 
-/* ---- update_alpha (host: ordered product over N*K, mcmc.c:1254-1260) ---- */
+/* ---- update_alpha (mcmc.c:1244-1263): factors on the device, ordered product on the host ---- */
 extern "C" int isg_update_alpha(isg_ctx *c)
 {
-	const int N = c->cfg.N, K = c->cfg.K;
+	HIPCHK(hipSetDevice(c->cfg.device));
+	const size_t NK = (size_t)c->cfg.N * c->cfg.K;
 	if (is_keyed(c)) host_seek(c, iter_base(c) + c->ky[KY_OFFA]);
 	isg_cursor cur;
 	cur.s = c->rng;
@@ -1806,12 +1907,14 @@ extern "C" int isg_update_alpha(isg_ctx *c)
 	c->rng = cur.s;
 	c->raw_valid = false;
 	if (ralpha > 0) {
+		prof_begin(c);
+		hipLaunchKernelGGL(k_alpha_ratios, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, c->stream, c->d, ralpha, c->alpha, c->d_ratios);
+		prof_end(c, "k_alpha_ratios");
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(c->ratios_h.data(), c->d_ratios, sizeof(double) * NK, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
 		double mh = 1.0;
-		for (int i = 0; i < N; i++)
-			for (int m = 0; m < K; m++) {
-				double q = c->qq[(size_t)i * K + m], n = (double)c->qqnum[(size_t)i * K + m];
-				mh *= isg_pow(q, ralpha + n) / isg_pow(q, n + c->alpha);
-			}
+		for (size_t k = 0; k < NK; k++) mh *= c->ratios_h[k]; /* in the reference's order: overflow to inf, 0 and NaN included */
 		double thr = (1 > mh) ? mh : 1;
 		c->alpha = (host_next(c) < thr) ? ralpha : c->alpha;
 	}
@@ -1826,13 +1929,11 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 	prof_begin(c);
 	hipLaunchKernelGGL((k_loglik<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
 	prof_end(c, "k_loglik_lkh");
+	prof_begin(c);
+	hipLaunchKernelGGL(k_lkh_total<1024>, dim3(1), dim3(1024), 0, c->stream, d, c->d_total);
+	prof_end(c, "k_lkh_total");
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpyAsync(c->indvlkh.data(), d.indvlkh, sizeof(double) * c->indvlkh.size(), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
-	isg_acc acc;
-	isg_acc_zero(&acc);
-	for (int i = 0; i < c->cfg.N; i++) isg_acc_add(&acc, c->indvlkh[i]);
-	c->totallkh = isg_acc_value(&acc);
+	c->h_lkh = false;
 	return 0;
 }
 
@@ -1886,6 +1987,10 @@ extern "C" int isg_chain_init(isg_ctx *c, const float *initd)
 			}
 		}
 		HIPCHK(hipMemcpyAsync(c->d.gen, c->gen.data(), sizeof(int) * N, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(c->d_S, c->S.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(c->d_state, c->state.data(), sizeof(int) * K, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		c->h_gen = c->h_S = true;
 	}
 	return isg_update_ZQ(c, 1);
 }
@@ -1936,34 +2041,81 @@ extern "C" int isg_set_freq(isg_ctx *c, const double *f)
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return 0;
 }
-extern "C" int isg_get_qq(isg_ctx *c, double *q) { memcpy(q, c->qq.data(), sizeof(double) * c->qq.size()); return 0; }
+extern "C" int isg_get_qq(isg_ctx *c, double *q)
+{
+	HIPCHK(hipSetDevice(c->cfg.device));
+	if (ensure_qq(c)) return 1;
+	memcpy(q, c->qq.data(), sizeof(double) * c->qq.size());
+	return 0;
+}
 extern "C" int isg_set_qq(isg_ctx *c, const double *q)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
+	if (ensure_qq(c)) return 1; /* keeps qqnum */
 	memcpy(c->qq.data(), q, sizeof(double) * c->qq.size());
 	HIPCHK(hipMemcpy(c->d.qq, q, sizeof(double) * c->qq.size(), hipMemcpyHostToDevice));
 	return 0;
 }
 extern "C" int isg_get_qqnum(isg_ctx *c, double *q)
 {
+	HIPCHK(hipSetDevice(c->cfg.device));
+	if (ensure_qq(c)) return 1;
 	for (size_t i = 0; i < c->qqnum.size(); i++) q[i] = (double)c->qqnum[i];
 	return 0;
 }
-extern "C" int isg_get_generation(isg_ctx *c, int32_t *g) { memcpy(g, c->gen.data(), sizeof(int) * c->gen.size()); return 0; }
+extern "C" int isg_get_generation(isg_ctx *c, int32_t *g)
+{
+	HIPCHK(hipSetDevice(c->cfg.device));
+	if (ensure_gen(c)) return 1;
+	memcpy(g, c->gen.data(), sizeof(int) * c->gen.size());
+	return 0;
+}
 extern "C" int isg_set_generation(isg_ctx *c, const int32_t *g)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
 	memcpy(c->gen.data(), g, sizeof(int) * c->gen.size());
 	HIPCHK(hipMemcpy(c->d.gen, g, sizeof(int) * c->gen.size(), hipMemcpyHostToDevice));
+	c->h_gen = true;
 	return 0;
 }
-extern "C" int isg_get_self_rates(isg_ctx *c, double *s) { memcpy(s, c->S.data(), sizeof(double) * c->S.size()); return 0; }
-extern "C" int isg_set_self_rates(isg_ctx *c, const double *s) { memcpy(c->S.data(), s, sizeof(double) * c->S.size()); return 0; }
-extern "C" int isg_get_state(isg_ctx *c, int32_t *s) { memcpy(s, c->state.data(), sizeof(int) * c->state.size()); return 0; }
-extern "C" int isg_get_indvlkh(isg_ctx *c, double *v) { memcpy(v, c->indvlkh.data(), sizeof(double) * c->indvlkh.size()); return 0; }
+extern "C" int isg_get_self_rates(isg_ctx *c, double *s)
+{
+	HIPCHK(hipSetDevice(c->cfg.device));
+	if (ensure_S(c)) return 1;
+	memcpy(s, c->S.data(), sizeof(double) * c->S.size());
+	return 0;
+}
+extern "C" int isg_set_self_rates(isg_ctx *c, const double *s)
+{
+	HIPCHK(hipSetDevice(c->cfg.device));
+	if (ensure_S(c)) return 1;
+	memcpy(c->S.data(), s, sizeof(double) * c->S.size());
+	HIPCHK(hipMemcpy(c->d_S, c->S.data(), sizeof(double) * c->cfg.K, hipMemcpyHostToDevice));
+	return 0;
+}
+extern "C" int isg_get_state(isg_ctx *c, int32_t *s)
+{
+	HIPCHK(hipSetDevice(c->cfg.device));
+	if (ensure_S(c)) return 1;
+	memcpy(s, c->state.data(), sizeof(int) * c->state.size());
+	return 0;
+}
+extern "C" int isg_get_indvlkh(isg_ctx *c, double *v)
+{
+	HIPCHK(hipSetDevice(c->cfg.device));
+	if (ensure_lkh(c)) return 1;
+	memcpy(v, c->indvlkh.data(), sizeof(double) * c->indvlkh.size());
+	return 0;
+}
 extern "C" int isg_get_alpha(isg_ctx *c, double *a) { *a = c->alpha; return 0; }
 extern "C" int isg_set_alpha(isg_ctx *c, double a) { c->alpha = a; return 0; }
-extern "C" int isg_get_totallkh(isg_ctx *c, double *t) { *t = c->totallkh; return 0; }
+extern "C" int isg_get_totallkh(isg_ctx *c, double *t)
+{
+	HIPCHK(hipSetDevice(c->cfg.device));
+	if (ensure_lkh(c)) return 1;
+	*t = c->totallkh;
+	return 0;
+}
 
 /* ---- profiling ---- */
 extern "C" int isg_profile_enable(isg_ctx *c, int on) { c->prof = on != 0; return 0; }
