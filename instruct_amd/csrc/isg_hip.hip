@@ -321,15 +321,54 @@ __global__ void __launch_bounds__(BLOCK) k_gprop(DevView d, const double *S, isg
 /* ------------------------------------------------------------------------------------------ */
 /* k_loglik: log_ld_indv (mcmc.c:1726-1773) for a proposal/current pair or for cal_lkh          */
 /* ------------------------------------------------------------------------------------------ */
+/* block reduction of the specialised accumulator (two 64-bit integer sums + flags) */
+template <int BLOCK>
+__device__ __forceinline__ isg_acc2 block_reduce_acc2(const isg_acc2 &a, long long *sm /* [BLOCK/64][3] */)
+{
+	const int NW = BLOCK / 64;
+	long long hi = a.hi, lo = a.lo;
+	unsigned fl = a.flags;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		hi += __shfl_down(hi, o, 64);
+		lo += __shfl_down(lo, o, 64);
+		fl |= __shfl_down(fl, o, 64);
+	}
+	const unsigned w = threadIdx.x >> 6;
+	if (lane_id() == 0) {
+		sm[w * 3 + 0] = hi;
+		sm[w * 3 + 1] = lo;
+		sm[w * 3 + 2] = (long long)fl;
+	}
+	__syncthreads();
+	isg_acc2 r;
+	r.hi = 0;
+	r.lo = 0;
+	r.flags = 0;
+	for (int i = 0; i < NW; i++) {
+		r.hi += sm[i * 3 + 0];
+		r.lo += sm[i * 3 + 1];
+		r.flags |= (unsigned)sm[i * 3 + 2];
+	}
+	__syncthreads();
+	return r;
+}
+
 /* PAIR = true : update_G -- both generations in one pass over the row, MH accept at the end
- * PAIR = false: cal_lkh  -- indvlkh[i] (mode 2: current generation; mode 1: log_ld_noselfing_indv) */
+ * PAIR = false: cal_lkh  -- indvlkh[i] (mode 2: current generation; mode 1: log_ld_noselfing_indv)
+ *
+ * Every locus contributes either log(genofreq(.., g)) (both copies assigned to the same cluster,
+ * mcmc.c:1752-1758, or -y 0, :1739-1748) or log f0 + log f1 (+ log 2) (:1760-1767, mode 1 :1881-1886).
+ * To keep the wave convergent each lane takes exactly two logarithms per locus -- of
+ * (genofreq(g_cur), genofreq(g_prop)) or of (f0, f1) -- and sorts the results into three
+ * order-independent accumulators: current-generation terms, proposed-generation terms, common terms. */
 template <int BLOCK, bool PAIR>
 __global__ void __launch_bounds__(BLOCK) k_loglik(DevView d)
 {
-	__shared__ unsigned long long sm[(BLOCK / 64) * 5];
+	__shared__ long long sm[(BLOCK / 64) * 3];
 	__shared__ double qsh[ISG_KCAP];
 	const int i = blockIdx.x;
-	int gp = 0, gc;
+	int gp = 1, gc;
 	if (PAIR) {
 		gp = d.genprop[i];
 		gc = d.gen[i];
@@ -337,15 +376,16 @@ __global__ void __launch_bounds__(BLOCK) k_loglik(DevView d)
 	} else {
 		gc = (d.mode == 2) ? d.gen[i] : -1;
 	}
-	if (d.type_freq == 0) {
+	const bool expect = (gc >= 0 && d.type_freq == 0); /* -y 0: expected frequencies under qq */
+	if (expect) {
 		if (threadIdx.x < (unsigned)d.K) qsh[threadIdx.x] = d.qq[(size_t)i * d.K + threadIdx.x];
 		__syncthreads();
 	}
 	const double log2c = isg_log(2.0);
-	isg_acc accC, accP, accX; /* current-gen terms, proposed-gen terms, generation-independent terms */
-	isg_acc_zero(&accC);
-	isg_acc_zero(&accP);
-	isg_acc_zero(&accX);
+	isg_acc2 accC, accP, accX; /* current-gen terms, proposed-gen terms, generation-independent terms */
+	isg_acc2_zero(&accC);
+	isg_acc2_zero(&accP);
+	isg_acc2_zero(&accX);
 	const size_t rowb = (size_t)d.Lp * 2;
 	const uint8_t *grow = d.geno + (size_t)i * rowb;
 	const uint8_t *zrow = d.z + (size_t)i * rowb;
@@ -357,43 +397,49 @@ __global__ void __launch_bounds__(BLOCK) k_loglik(DevView d)
 		for (int l = 0; l < ISG_LPT; l++) {
 			unsigned a0 = (unsigned)(gb >> (16 * l)) & 0xff, a1 = (unsigned)(gb >> (16 * l + 8)) & 0xff;
 			unsigned z0 = (unsigned)(zb >> (16 * l)) & 0xff, z1 = (unsigned)(zb >> (16 * l + 8)) & 0xff;
-			if (a0 == 0xff) continue;
-			const int j = j0 + l;
+			const bool valid = (a0 != 0xff);
+			if (!valid) { a0 = a1 = 0; z0 = z1 = 0; }
+			const int j = (j0 + l < d.L) ? j0 + l : 0;
 			const double *F0 = d.freq + ((size_t)j * d.Amax + a0) * d.KP;
 			const double *F1 = d.freq + ((size_t)j * d.Amax + a1) * d.KP;
-			if (gc < 0) { /* mode 1: mcmc.c:1881-1886 */
-				isg_acc_add(&accC, isg_log(F0[z0]));
-				isg_acc_add(&accC, isg_log(F1[z1]));
-				if (a0 != a1) isg_acc_add(&accC, log2c);
-			} else if (d.type_freq == 0) { /* mcmc.c:1739-1748 */
-				double t0 = 0, t1 = 0;
-				for (int m = 0; m < d.K; m++) t0 += F0[m] * qsh[m];
-				for (int m = 0; m < d.K; m++) t1 += F1[m] * qsh[m];
-				isg_acc_add(&accC, isg_log(isg_genofreq(a0 == a1, t0, t1, gc)));
-				if (PAIR) isg_acc_add(&accP, isg_log(isg_genofreq(a0 == a1, t0, t1, gp)));
-			} else if (z0 == z1) { /* mcmc.c:1752-1758 */
-				double f0 = F0[z0], f1 = F1[z1];
-				isg_acc_add(&accC, isg_log(isg_genofreq(a0 == a1, f0, f1, gc)));
-				if (PAIR) isg_acc_add(&accP, isg_log(isg_genofreq(a0 == a1, f0, f1, gp)));
-			} else { /* mcmc.c:1760-1767 */
-				isg_acc_add(&accX, isg_log(F0[z0]));
-				isg_acc_add(&accX, isg_log(F1[z1]));
-				if (a0 != a1) isg_acc_add(&accX, log2c);
+			double f0, f1;
+			if (expect) {
+				f0 = 0;
+				f1 = 0;
+				for (int m = 0; m < d.K; m++) f0 += F0[m] * qsh[m];
+				for (int m = 0; m < d.K; m++) f1 += F1[m] * qsh[m];
+			} else {
+				f0 = F0[z0];
+				f1 = F1[z1];
 			}
+			const bool geno_term = expect || (gc >= 0 && z0 == z1);
+			const bool hom = (a0 == a1);
+			double v0 = f0, v1 = f1;
+			if (gc >= 0) { /* wave-uniform */
+				const double gfc = isg_genofreq(hom, f0, f1, gc), gfp = PAIR ? isg_genofreq(hom, f0, f1, gp) : 1.0;
+				v0 = geno_term ? gfc : f0;
+				v1 = geno_term ? gfp : f1;
+			}
+			const double L0 = isg_log(v0), L1 = isg_log(v1);
+			isg_acc2_add(&accC, (valid && geno_term) ? L0 : 0.0);
+			if (PAIR) isg_acc2_add(&accP, (valid && geno_term) ? L1 : 0.0);
+			isg_acc2_add(&accX, (valid && !geno_term) ? L0 : 0.0);
+			isg_acc2_add(&accX, (valid && !geno_term) ? L1 : 0.0);
+			isg_acc2_add(&accX, (valid && !geno_term && !hom) ? log2c : 0.0);
 		}
 	}
-	isg_acc rc, rp, rx;
-	rc = block_reduce_acc<BLOCK>(accC, sm);
-	rx = block_reduce_acc<BLOCK>(accX, sm);
-	if (PAIR) rp = block_reduce_acc<BLOCK>(accP, sm);
+	isg_acc2 rc, rp, rx;
+	rc = block_reduce_acc2<BLOCK>(accC, sm);
+	rx = block_reduce_acc2<BLOCK>(accX, sm);
+	if (PAIR) rp = block_reduce_acc2<BLOCK>(accP, sm);
 	if (threadIdx.x == 0) {
-		isg_acc tc = rc;
-		isg_acc_merge(&tc, &rx);
-		double lc = isg_acc_value(&tc);
+		isg_acc2 tc = rc;
+		isg_acc2_merge(&tc, &rx);
+		double lc = isg_acc2_value(&tc);
 		if (PAIR) {
-			isg_acc tp = rp;
-			isg_acc_merge(&tp, &rx);
-			double lp = isg_acc_value(&tp);
+			isg_acc2 tp = rp;
+			isg_acc2_merge(&tp, &rx);
+			double lp = isg_acc2_value(&tp);
 			double mh = isg_exp(lp - lc);
 			double thr = (1 > mh) ? mh : 1; /* MIN2(1, mhratio), mcmc.h:10 */
 			if (d.uacc[i] < thr) d.gen[i] = gp;

@@ -329,4 +329,51 @@ ISG_HD double isg_acc_value(const isg_acc *a)
 	return neg ? -r : r;
 }
 
+/*
+ * Order-independent accumulation specialised for terms of magnitude < 1024 (single log-probabilities:
+ * the per-locus terms of log_ld_indv, mcmc.c:1735-1770).  A term v is split exactly into
+ *     v = h * 2^-20 + m * 2^-51 + r,   h = rint(v * 2^20),  m = rint((v - h * 2^-20) * 2^51),  |r| <= 2^-52
+ * and the integers h, m are summed (associative); r is dropped.  A dozen instructions per term instead
+ * of the generic isg_acc's variable shifts.  -inf / NaN / out-of-range terms are tracked in flags.
+ */
+typedef struct {
+	int64_t hi, lo;
+	uint32_t flags; /* 1: +inf, 2: -inf, 4: nan or |v| >= 1024 */
+} isg_acc2;
+
+ISG_HD void isg_acc2_zero(isg_acc2 *a)
+{
+	a->hi = 0;
+	a->lo = 0;
+	a->flags = 0;
+}
+ISG_HD void isg_acc2_add(isg_acc2 *a, double v)
+{
+	double hs, lo, ms;
+	if (!(v > -1024.0 && v < 1024.0)) {
+		uint64_t u = isg_d2u(v);
+		a->flags |= (u == 0x7ff0000000000000ULL) ? 1u : (u == 0xfff0000000000000ULL) ? 2u : 4u;
+		return;
+	}
+	hs = __builtin_rint(v * 1048576.0);
+	lo = isg_fma(hs, -0x1p-20, v); /* exact */
+	ms = __builtin_rint(lo * 0x1p51);
+	a->hi += (int64_t)(int32_t)hs;
+	a->lo += (int64_t)(int32_t)ms;
+}
+ISG_HD void isg_acc2_merge(isg_acc2 *a, const isg_acc2 *b)
+{
+	a->hi += b->hi;
+	a->lo += b->lo;
+	a->flags |= b->flags;
+}
+ISG_HD double isg_acc2_value(const isg_acc2 *a)
+{
+	if (a->flags & 4u) return isg_nan();
+	if ((a->flags & 3u) == 3u) return isg_nan();
+	if (a->flags & 1u) return isg_inf();
+	if (a->flags & 2u) return -isg_inf();
+	return (double)a->hi * 0x1p-20 + (double)a->lo * 0x1p-51;
+}
+
 #endif /* ISG_MATH_H */

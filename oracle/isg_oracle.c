@@ -217,23 +217,28 @@ typedef struct { double s; isg_acc a; int exact; } summer;
 static void sum_init(summer *s, int exact) { s->s = 0; s->exact = exact; isg_acc_zero(&s->a); }
 static void sum_add(summer *s, double v) { if (s->exact) isg_acc_add(&s->a, v); else s->s += v; }
 static double sum_val(const summer *s) { return s->exact ? isg_acc_value(&s->a) : s->s; }
+/* per-locus log-probability terms (|v| < 1024): the specialised accumulator of isg_math.h */
+typedef struct { double s; isg_acc2 a; int exact; } summer2;
+static void sum2_init(summer2 *s, int exact) { s->s = 0; s->exact = exact; isg_acc2_zero(&s->a); }
+static void sum2_add(summer2 *s, double v) { if (s->exact) isg_acc2_add(&s->a, v); else s->s += v; }
+static double sum2_val(const summer2 *s) { return s->exact ? isg_acc2_value(&s->a) : s->s; }
 
 /* mcmc.c:1726-1773 (diploid); mode 1's log_ld_noselfing_indv (mcmc.c:1869-1890) when gen < 0 */
 static double log_ld_indv(const orc_chain *c, int gen, int i)
 {
 	int j, m, k;
-	summer t;
+	summer2 t;
 	const int K = c->p.K;
-	sum_init(&t, c->p.accum);
+	sum2_init(&t, c->p.accum);
 	for (j = 0; j < c->p.L; j++) {
 		int a0, a1, z0, z1;
 		if (!c->valid[(long)i * c->p.L + j]) continue;
 		a0 = GENO(c, i, j, 0); a1 = GENO(c, i, j, 1);
 		z0 = ZZ(c, i, j, 0); z1 = ZZ(c, i, j, 1);
 		if (gen < 0) { /* mode 1 */
-			sum_add(&t, m_log(c, FREQ(c, z0, j, a0)));
-			sum_add(&t, m_log(c, FREQ(c, z1, j, a1)));
-			if (a0 != a1) sum_add(&t, m_log(c, 2));
+			sum2_add(&t, m_log(c, FREQ(c, z0, j, a0)));
+			sum2_add(&t, m_log(c, FREQ(c, z1, j, a1)));
+			if (a0 != a1) sum2_add(&t, m_log(c, 2));
 			continue;
 		}
 		if (c->p.type_freq == 0) {
@@ -243,18 +248,18 @@ static double log_ld_indv(const orc_chain *c, int gen, int i)
 				tmp[k] = 0;
 				for (m = 0; m < K; m++) tmp[k] += FREQ(c, m, j, a) * c->qq[(long)i * K + m];
 			}
-			sum_add(&t, m_log(c, genofreq(c, a0, a1, tmp[0], tmp[1], gen)));
+			sum2_add(&t, m_log(c, genofreq(c, a0, a1, tmp[0], tmp[1], gen)));
 		} else {
 			if (z0 == z1) {
-				sum_add(&t, m_log(c, genofreq(c, a0, a1, FREQ(c, z0, j, a0), FREQ(c, z1, j, a1), gen)));
+				sum2_add(&t, m_log(c, genofreq(c, a0, a1, FREQ(c, z0, j, a0), FREQ(c, z1, j, a1), gen)));
 			} else {
-				sum_add(&t, m_log(c, FREQ(c, z0, j, a0)));
-				sum_add(&t, m_log(c, FREQ(c, z1, j, a1)));
-				if (a0 != a1) sum_add(&t, m_log(c, 2));
+				sum2_add(&t, m_log(c, FREQ(c, z0, j, a0)));
+				sum2_add(&t, m_log(c, FREQ(c, z1, j, a1)));
+				if (a0 != a1) sum2_add(&t, m_log(c, 2));
 			}
 		}
 	}
-	return sum_val(&t);
+	return sum2_val(&t);
 }
 
 static int dt_stat(orc_chain *c, double num) /* mcmc.c:1524-1546 */
