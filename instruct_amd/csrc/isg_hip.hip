@@ -232,26 +232,33 @@ __device__ __forceinline__ isg_acc block_reduce_acc(const isg_acc &a, unsigned l
  * in the workgroup touches its counters, so plain LDS read-modify-writes suffice.
  * LDS layout lds[c * BLOCK + t], c = (l * Amax + a) * K + k  -> bank = t mod 32: conflict free.
  */
-template <int BLOCK>
+template <int BLOCK, int LPT>
 __global__ void __launch_bounds__(BLOCK) k_count(DevView d, int rows_per_block)
 {
 	extern __shared__ unsigned lds_cnt[];
-	const int C = ISG_LPT * d.Amax * d.K;
+	const int C = LPT * d.Amax * d.K;
 	const int t = threadIdx.x;
 	for (int c = 0; c < C; c++) lds_cnt[c * BLOCK + t] = 0;
-	const int J0 = blockIdx.x * BLOCK * ISG_LPT;
-	const int j0 = J0 + t * ISG_LPT;
+	const int J0 = blockIdx.x * BLOCK * LPT;
+	const int j0 = J0 + t * LPT;
 	const int r0 = blockIdx.y * rows_per_block;
 	int r1 = r0 + rows_per_block;
 	if (r1 > d.N) r1 = d.N;
 	const size_t rowb = (size_t)d.Lp * 2;
 	if (j0 < d.Lp) {
 		for (int i = r0; i < r1; i++) {
-			const uint2 g = *(const uint2 *)(d.geno + (size_t)i * rowb + (size_t)j0 * 2);
-			const uint2 zz = *(const uint2 *)(d.z + (size_t)i * rowb + (size_t)j0 * 2);
-			unsigned long long gb = ((unsigned long long)g.y << 32) | g.x, zb = ((unsigned long long)zz.y << 32) | zz.x;
+			unsigned long long gb, zb;
+			if (LPT == 4) {
+				const uint2 g = *(const uint2 *)(d.geno + (size_t)i * rowb + (size_t)j0 * 2);
+				const uint2 zz = *(const uint2 *)(d.z + (size_t)i * rowb + (size_t)j0 * 2);
+				gb = ((unsigned long long)g.y << 32) | g.x;
+				zb = ((unsigned long long)zz.y << 32) | zz.x;
+			} else {
+				gb = *(const unsigned short *)(d.geno + (size_t)i * rowb + (size_t)j0 * 2);
+				zb = *(const unsigned short *)(d.z + (size_t)i * rowb + (size_t)j0 * 2);
+			}
 #pragma unroll
-			for (int l = 0; l < ISG_LPT; l++) {
+			for (int l = 0; l < LPT; l++) {
 				unsigned a0 = (unsigned)(gb >> (16 * l)) & 0xff, a1 = (unsigned)(gb >> (16 * l + 8)) & 0xff;
 				unsigned z0 = (unsigned)(zb >> (16 * l)) & 0xff, z1 = (unsigned)(zb >> (16 * l + 8)) & 0xff;
 				if (a0 != 0xff) {
@@ -265,14 +272,27 @@ __global__ void __launch_bounds__(BLOCK) k_count(DevView d, int rows_per_block)
 	/* flush in global order: element e of the tile's contiguous [locus][a][k] range */
 	const int per_locus = d.Amax * d.K;
 	int tile_loci = d.L - J0;
-	if (tile_loci > BLOCK * ISG_LPT) tile_loci = BLOCK * ISG_LPT;
+	if (tile_loci > BLOCK * LPT) tile_loci = BLOCK * LPT;
 	if (tile_loci < 0) tile_loci = 0;
 	const int E = tile_loci * per_locus;
 	for (int e = t; e < E; e += BLOCK) {
 		int jl = e / per_locus, rem = e - jl * per_locus; /* rem = a*K + k */
-		unsigned v = lds_cnt[((jl % ISG_LPT) * per_locus + rem) * BLOCK + jl / ISG_LPT];
+		unsigned v = lds_cnt[((jl % LPT) * per_locus + rem) * BLOCK + jl / LPT];
 		if (v) atomicAdd(&d.cnt[(size_t)J0 * per_locus + e], (int)v);
 	}
+}
+
+/* fallback for very large Amax*K (tile counters do not fit in LDS): one global atomic per allele copy */
+__global__ void k_count_atomic(DevView d)
+{
+	const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= (size_t)d.N * d.Lp) return;
+	const unsigned short g = ((const unsigned short *)d.geno)[id], z = ((const unsigned short *)d.z)[id];
+	const unsigned a0 = g & 0xff, a1 = g >> 8;
+	if (a0 == 0xff) return;
+	const size_t j = id % d.Lp;
+	atomicAdd(&d.cnt[(j * d.Amax + a0) * d.K + (z & 0xff)], 1);
+	atomicAdd(&d.cnt[(j * d.Amax + a1) * d.K + (z >> 8)], 1);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -588,8 +608,11 @@ struct ZqShared {
 template <int BLOCK, int KMAX>
 __device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &sh, int i, isg_wh dstart, double alpha, int par,
 						   const double *dtape = nullptr, unsigned long long *pub = nullptr,
-						   unsigned long long pub_base = 0, unsigned long long pub_tag = 0)
+						   unsigned long long pub_base = 0, unsigned long long pub_tag = 0,
+						   unsigned long long dstart_off = 0)
 {
+	/* the generator state at the Dirichlet's first position is jump(dstart, dstart_off): the cooperative
+	 * kernel keeps only the offset from the start of the phase while the tape covers the draws */
 	const int K = d.K, t = threadIdx.x;
 	int *hist = sh.hist[par];
 	int noff = BLOCK / K;
@@ -600,7 +623,7 @@ __device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &
 		isg_cursor c;
 		c.used = 0;
 		c.tape = dtape ? dtape + 2 * o : nullptr; /* uniforms of this stretch already on the tape */
-		if (!dtape) c.s = isg_wh_jump32(&sh.tab, dstart, 2u * (unsigned)o);
+		if (!dtape) c.s = isg_wh_jump(&sh.tab, dstart, dstart_off + 2ull * (unsigned)o);
 		double r = -1;
 		if (a < 1) r = isg_rgamma1_try(&c, a);
 		else if (a > 1) r = isg_rgamma2_try(&c, a);
@@ -654,7 +677,7 @@ __device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &
 		if (t == 0) {
 			if (!ok) { /* continue sequentially from (gamma m, offset off) */
 				isg_cursor c;
-				c.s = isg_wh_jump32(&sh.tab, dstart, off);
+				c.s = isg_wh_jump(&sh.tab, dstart, dstart_off + off);
 				c.used = 0;
 				c.tape = nullptr;
 				for (int mm = m; mm < K; mm++) sh.gval[mm] = isg_rgamma(&c, (double)hist[mm] + alpha);
@@ -746,11 +769,7 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 	const bool fast = (nvalid == d.L);
 	/* the tape covers this individual's Z draws? (it always does unless the Dirichlets consumed far
 	 * more than budgeted; then the uniforms are generated on the fly) */
-#ifdef ISG_ABL_NOTAPE
-	const bool taped = false;
-#else
 	const bool taped = CHAIN && d.tape != nullptr && off + 2ull * (unsigned)nvalid <= d.tape_len;
-#endif
 	double q[KMAX];
 	float qf[KMAX];
 #pragma unroll
@@ -790,11 +809,7 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 				unsigned a0 = (unsigned)(gb >> (16 * l)) & 0xff, a1 = (unsigned)(gb >> (16 * l + 8)) & 0xff;
 				const int j = (j0 + l < d.L) ? j0 + l : 0;
 				if (a0 == 0xff) { a0 = 0; a1 = 0; }
-#ifdef ISG_ABL_NOROWS
-				const float *F0 = d.freqf + (size_t)(a0 & 1) * d.KPF, *F1 = d.freqf + (size_t)(a1 & 1) * d.KPF;
-#else
 				const float *F0 = d.freqf + ((size_t)j * d.Amax + a0) * d.KPF, *F1 = d.freqf + ((size_t)j * d.Amax + a1) * d.KPF;
-#endif
 #pragma unroll
 				for (int m = 0; m < KMAX; m += 4) {
 					if (m < K) {
@@ -859,17 +874,11 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 		} else if (HOIST) {
 #pragma unroll
 			for (int l = 0; l < ISG_LPT; l++) {
-#ifdef ISG_ABL_NOBUCKET
-				zz[2 * l] = (x[2 * l] > 0.5) ? 1 : 0;
-				zz[2 * l + 1] = (x[2 * l + 1] > 0.5) ? 1 : 0;
-				if (R0[l][0] + R1[l][0] + qf[0] == 123.f) redo = 1;
-#else
 				bool amb;
 				zz[2 * l] = bucket_f32<KMAX>((float)x[2 * l], R0[l], qf, K, &amb);
 				redo |= amb ? (1u << (2 * l)) : 0u;
 				zz[2 * l + 1] = bucket_f32<KMAX>((float)x[2 * l + 1], R1[l], qf, K, &amb);
 				redo |= amb ? (2u << (2 * l)) : 0u;
-#endif
 			}
 		} else {
 			redo = 0xffu;
@@ -895,25 +904,17 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 		for (int l = 0; l < ISG_LPT; l++) {
 			const bool valid = (((unsigned)(gb >> (16 * l)) & 0xff) != 0xff);
 			const int z0 = valid ? zz[2 * l] : 0xff, z1 = valid ? zz[2 * l + 1] : 0xff; /* 0xff: locus unused */
-#ifndef ISG_ABL_NOBALLOT
 #pragma unroll
 			for (int m = 0; m < KMAX; m++)
 				if (m < K) wcnt[m] += __popcll(__ballot(z0 == m)) + __popcll(__ballot(z1 == m));
-#else
-			wcnt[0] += z0 + z1;
-#endif
 			zb = (zb & ~(0xffffull << (16 * l))) | ((unsigned long long)(z0 | (z1 << 8)) << (16 * l));
 		}
-#ifndef ISG_ABL_NOSTORE
 		if (j0 < d.Lp) {
 			uint2 zo;
 			zo.x = (unsigned)zb;
 			zo.y = (unsigned)(zb >> 32);
 			*(uint2 *)(zrow + (size_t)j0 * 2) = zo;
 		}
-#else
-		if (zb == 0x1234567ull) d.err[0] = 1; /* keep zb alive */
-#endif
 		gb = gnext;
 	}
 	STAMP(i, 1);
@@ -1214,13 +1215,12 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 			lds_barrier();
 			STAMP(i, 7);
 			if (!covered && t == 0) cb->overflow_flag = 1;
-			/* the generator state is only needed when the tape does not cover the Dirichlet's stretch */
-			isg_wh dstart = cur;
-			if (!covered) dstart = isg_wh_jump(&sh.tab, base, off + 2ull * (unsigned)nvalid);
+			/* generator state = jump(cur, off + 2 nvalid): only evaluated where the tape is not used */
 			const unsigned used = 2u * (unsigned)nvalid +
-				dirichlet_block<BLOCK, KMAX>(d, sh, i, dstart, alpha, par, covered ? d.tape + offi + 2ull * (unsigned)nvalid : nullptr,
+				dirichlet_block<BLOCK, KMAX>(d, sh, i, cur, alpha, par, covered ? d.tape + offi + 2ull * (unsigned)nvalid : nullptr,
 							     (i + 1 < d.N) ? &cb->pos[(i + 1) & (ISG_COOP_RING - 1)] : nullptr,
-							     off + 2ull * (unsigned)nvalid, (unsigned long long)((unsigned)((i + 1) % 65535) + 1u));
+							     off + 2ull * (unsigned)nvalid, (unsigned long long)((unsigned)((i + 1) % 65535) + 1u),
+							     off + 2ull * (unsigned)nvalid);
 			off += used;
 		}
 	}
@@ -1716,28 +1716,38 @@ static int ensure_lkh(isg_ctx *c)
 }
 
 /* ---- counts ---- */
-static int launch_count(isg_ctx *c)
+template <int BLOCK, int LPT>
+static int launch_count_tile(isg_ctx *c)
 {
 	DevView &d = c->d;
-	const int BLOCK = 256;
-	size_t lds = (size_t)ISG_LPT * d.Amax * d.K * BLOCK * sizeof(unsigned);
-	if (lds > 160 * 1024) return fail("isg_count_alleles: Amax*K too large for the LDS-resident count tile of this build");
-	HIPCHK(hipMemsetAsync(d.cnt, 0, sizeof(int) * (size_t)d.L * d.Amax * d.K, c->stream));
-	int tiles = (d.Lp + BLOCK * ISG_LPT - 1) / (BLOCK * ISG_LPT);
-	int want_blocks = 1024;
-	int rb = (want_blocks + tiles - 1) / tiles;
+	const size_t lds = (size_t)LPT * d.Amax * d.K * BLOCK * sizeof(unsigned);
+	int tiles = (d.Lp + BLOCK * LPT - 1) / (BLOCK * LPT);
+	int rb = (1024 + tiles - 1) / tiles; /* about a thousand workgroups */
 	if (rb > d.N) rb = d.N;
 	if (rb < 1) rb = 1;
 	int rows = (d.N + rb - 1) / rb;
 	rb = (d.N + rows - 1) / rows;
-	static bool attr_set = false;
-	if (!attr_set) {
-		HIPCHK(hipFuncSetAttribute((const void *)k_count<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		attr_set = true;
-	}
+	HIPCHK(hipFuncSetAttribute((const void *)k_count<BLOCK, LPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	prof_begin(c);
-	hipLaunchKernelGGL(k_count<256>, dim3(tiles, rb), dim3(BLOCK), lds, c->stream, d, rows);
+	hipLaunchKernelGGL((k_count<BLOCK, LPT>), dim3(tiles, rb), dim3(BLOCK), lds, c->stream, d, rows);
 	prof_end(c, "k_count");
+	return 0;
+}
+static int launch_count(isg_ctx *c)
+{
+	DevView &d = c->d;
+	HIPCHK(hipMemsetAsync(d.cnt, 0, sizeof(int) * (size_t)d.L * d.Amax * d.K, c->stream));
+	const size_t per_lane = (size_t)d.Amax * d.K * sizeof(unsigned); /* LDS bytes per lane and locus */
+	const size_t cap = 150 * 1024;
+	if (4 * per_lane * 256 <= cap) { if (launch_count_tile<256, 4>(c)) return 1; }
+	else if (per_lane * 256 <= cap) { if (launch_count_tile<256, 1>(c)) return 1; }
+	else if (per_lane * 64 <= cap) { if (launch_count_tile<64, 1>(c)) return 1; }
+	else {
+		const size_t n = (size_t)d.N * d.Lp;
+		prof_begin(c);
+		hipLaunchKernelGGL(k_count_atomic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d);
+		prof_end(c, "k_count_atomic");
+	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }

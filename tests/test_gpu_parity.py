@@ -90,6 +90,40 @@ def test_every_sweep_bit_exact_vs_canonical_oracle(case, sched):
     h.close()
 
 
+EDGE_CASES = [
+    # N, L, K, alleles, missing, note
+    (40, 60, 6, 12, 0.05),     # microsatellite-like: count tile variant <256 lanes, 1 locus per lane>
+    (20, 30, 20, 15, 0.05),    # Amax*K = 300: count tile variant <64, 1>; K > 16 kernel variant
+    (12, 20, 32, 30, 0.0),     # Amax*K = 960: global-atomic count fallback; K = 32
+    (9, 40, 1, 2, 0.1),        # a single cluster
+    (2, 3, 2, 2, 0.0),         # two individuals, three loci
+    (6, 70, 3, 2, 0.5),        # half of everything missing
+]
+
+
+@pytest.mark.parametrize("sched", [capi.SCHED_REPLAY, capi.SCHED_KEYED])
+@pytest.mark.parametrize("case", EDGE_CASES)
+def test_edge_shapes_bit_exact_vs_canonical_oracle(case, sched):
+    N, L, K, nall, miss = case
+    raw = synth.raw_alleles(N, L, max(K, 2), 2, nall, miss, 11)
+    if N >= 6:
+        raw[2] = synth.MISSING          # an individual without any usable locus
+    if N == 2:
+        raw[0, :, 0], raw[0, :, 1], raw[1, :, 0], raw[1, :, 1] = 1, 2, 2, 2   # keep every locus polymorphic
+    geno, an, mi = synth.code_diploid(raw)
+    h, o, initd = _pair(geno, an, mi, K, sched)
+    assert h.keyed_layout() == o.keyed_layout()
+    h.chain_init(initd)
+    o.chain_init(initd)
+    for it in range(3):
+        h.iteration()
+        o.iteration()
+        _same(h, o, ["z", "qq", "qqnum", "generation", "alpha", "self_rates", "freq", "count_alleles", "indvlkh", "totallkh"], it)
+        if sched == capi.SCHED_REPLAY:
+            assert h.seeds() == o.seeds()
+    h.close()
+
+
 def _counts_hash(cnt, an):
     K, L, A = cnt.shape
     mask = np.arange(A)[None, :] < an[:, None]
