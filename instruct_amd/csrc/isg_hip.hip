@@ -728,9 +728,10 @@ __device__ __forceinline__ void zq_prefetch(const DevView &d, int i, int init_fl
 /*
  * Single precision pre-filter of one Z draw.  The bucket is the number of m <= K-2 with
  * fl(cum[m]/tot) < x (see bucket_fast).  Evaluated in float the sign of x*tot - cum[m] is right
- * whenever it clears a guard band of 4e-6*tot (the float rounding of qq, freq, the K-term sums and x
- * stays below 1.5e-6*tot); otherwise `amb` is raised and the caller redoes THIS draw in double
- * (bucket_fast), so the returned Z is always the reference's.  About 3 draws in 100000 are redone.
+ * whenever it clears a guard band of 6e-6*tot (the float rounding of qq, freq, the K-term sums and of
+ * the float-evaluated uniform stays below 2e-6*tot); otherwise, or when x is within 4e-6 of 0 or 1,
+ * `amb` is raised and the caller redoes THIS draw in double (bucket_fast), so the returned Z is always
+ * the reference's.  About 5 draws in 100000 are redone.
  */
 template <int KMAX>
 __device__ __forceinline__ int bucket_f32(float xf, const float (&F)[KMAX], const float (&qf)[KMAX], int K, bool *amb)
@@ -741,8 +742,8 @@ __device__ __forceinline__ int bucket_f32(float xf, const float (&F)[KMAX], cons
 		if (m < K) run = (m == 0) ? qf[m] * F[m] : run + qf[m] * F[m];
 		cum[m] = run;
 	}
-	const float p = xf * run, marg = 4e-6f * run;
-	bool a = !(run > 1e-30f && run < 1e30f);
+	const float p = xf * run, marg = 6e-6f * run;
+	bool a = !(run > 1e-30f && run < 1e30f) || !(xf > 4e-6f && xf < 1.0f - 4e-6f);
 	int z = 0;
 #pragma unroll
 	for (int m = 0; m < KMAX - 1; m++) {
@@ -834,7 +835,12 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 			rank = running + block_excl_scan<BLOCK>(nv, sh.scan, &tot);
 			running += tot;
 		}
+		/* `x` holds the exact uniforms when they come from the tape; when they are generated here only
+		 * the packed generator states are kept: the float pre-filter needs a float value, the exact
+		 * double is formed just for the few draws that are redone */
 		double x[2 * ISG_LPT];
+		float xf[2 * ISG_LPT];
+		unsigned long long st[2 * ISG_LPT];
 		if (taped) {
 			const double *tp = d.tape + off + 2ull * rank;
 			unsigned k = 0;
@@ -843,6 +849,8 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 				const bool valid = (((unsigned)(gb >> (16 * l)) & 0xff) != 0xff);
 				x[2 * l] = valid ? tp[k] : 0.0;
 				x[2 * l + 1] = valid ? tp[k + 1] : 0.0;
+				xf[2 * l] = (float)x[2 * l];
+				xf[2 * l + 1] = (float)x[2 * l + 1];
 				k += valid ? 2u : 0u;
 			}
 		} else {
@@ -857,27 +865,39 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 			for (int l = 0; l < ISG_LPT; l++) {
 				const bool valid = (((unsigned)(gb >> (16 * l)) & 0xff) != 0xff);
 				isg_wh s2 = s;
-				x[2 * l] = isg_wh_next(&s2);
-				x[2 * l + 1] = isg_wh_next(&s2);
+#pragma unroll
+				for (int cp = 0; cp < 2; cp++) {
+					isg_wh_step(&s2);
+					st[2 * l + cp] = (unsigned long long)s2.s1 | ((unsigned long long)s2.s2 << 16) | ((unsigned long long)s2.s3 << 32);
+					xf[2 * l + cp] = isg_wh_value_f32(&s2);
+				}
 				s.s1 = valid ? s2.s1 : s.s1; /* unused loci consume nothing (mcmc.c:1137) */
 				s.s2 = valid ? s2.s2 : s.s2;
 				s.s3 = valid ? s2.s3 : s.s3;
 			}
 		}
+		auto exact_x = [&](int c8) -> double {
+			if (taped) return x[c8];
+			isg_wh e;
+			e.s1 = (uint32_t)(st[c8] & 0xffff);
+			e.s2 = (uint32_t)((st[c8] >> 16) & 0xffff);
+			e.s3 = (uint32_t)((st[c8] >> 32) & 0xffff);
+			return isg_wh_value(&e);
+		};
 		/* phase 3: buckets.  Straight-line float pre-filter over the 8 copies; flagged draws are redone
 		 * in double afterwards (rare), so no data-dependent branch sits between the dependency chains. */
 		int zz[2 * ISG_LPT];
 		unsigned redo = 0;
 		if (init_flag) {
 #pragma unroll
-			for (int c8 = 0; c8 < 2 * ISG_LPT; c8++) zz[c8] = bucket_fast<KMAX>(x[c8], icum, 1.0, K); /* vec[K-1] = K/K */
+			for (int c8 = 0; c8 < 2 * ISG_LPT; c8++) zz[c8] = bucket_fast<KMAX>(exact_x(c8), icum, 1.0, K); /* vec[K-1] = K/K */
 		} else if (HOIST) {
 #pragma unroll
 			for (int l = 0; l < ISG_LPT; l++) {
 				bool amb;
-				zz[2 * l] = bucket_f32<KMAX>((float)x[2 * l], R0[l], qf, K, &amb);
+				zz[2 * l] = bucket_f32<KMAX>(xf[2 * l], R0[l], qf, K, &amb);
 				redo |= amb ? (1u << (2 * l)) : 0u;
-				zz[2 * l + 1] = bucket_f32<KMAX>((float)x[2 * l + 1], R1[l], qf, K, &amb);
+				zz[2 * l + 1] = bucket_f32<KMAX>(xf[2 * l + 1], R1[l], qf, K, &amb);
 				redo |= amb ? (2u << (2 * l)) : 0u;
 			}
 		} else {
@@ -891,11 +911,11 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 				double cum[KMAX], tot;
 				if (redo & (1u << (2 * l))) {
 					tot = weights<KMAX>(d.freq + ((size_t)(j0 + l) * d.Amax + a0) * d.KP, q, cum, K);
-					zz[2 * l] = bucket_fast<KMAX>(x[2 * l], cum, tot, K);
+					zz[2 * l] = bucket_fast<KMAX>(exact_x(2 * l), cum, tot, K);
 				}
 				if (redo & (2u << (2 * l))) {
 					tot = weights<KMAX>(d.freq + ((size_t)(j0 + l) * d.Amax + a1) * d.KP, q, cum, K);
-					zz[2 * l + 1] = bucket_fast<KMAX>(x[2 * l + 1], cum, tot, K);
+					zz[2 * l + 1] = bucket_fast<KMAX>(exact_x(2 * l + 1), cum, tot, K);
 				}
 			}
 		}

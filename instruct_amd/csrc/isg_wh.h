@@ -54,12 +54,23 @@ static inline void isg_wh_tables_init(isg_wh_tables *t)
  */
 ISG_HD uint32_t isg_lcg_fast(uint32_t s, uint32_t a, uint32_t m, float invm)
 {
-	uint32_t p = a * s; /* fits 24 bits: the compiler selects v_mul_u32_u24 */
+#if defined(__HIP_DEVICE_COMPILE__)
+	uint32_t p = __umul24(a, s);
+	uint32_t q = (uint32_t)((float)p * invm);
+	uint32_t r = p - __umul24(q, m); /* in {-m .. 2m-1} mod 2^32 */
+	uint32_t r1 = r + m, r2;
+	r = r < r1 ? r : r1;             /* a "negative" r is huge as unsigned: r + m wraps to the small value */
+	r2 = r - m;
+	return r < r2 ? r : r2;          /* r < m: r - m wraps to a huge value */
+#else
+	uint32_t p = a * s;
 	uint32_t q = (uint32_t)((float)p * invm);
 	uint32_t r = p - q * m;
-	r = (r >= 0x80000000u) ? r + m : r;
-	r = (r >= m) ? r - m : r;
-	return r;
+	uint32_t r1 = r + m, r2;
+	r = r < r1 ? r : r1;
+	r2 = r - m;
+	return r < r2 ? r : r2;
+#endif
 }
 
 ISG_HD void isg_wh_step(isg_wh *s)
@@ -92,6 +103,16 @@ ISG_HD double isg_wh_value(const isg_wh *s)
 	/* fmod(x, 1.0) for 0 <= x < 3: both subtractions are exact */
 	if (x >= 2.0) x -= 2.0;
 	else if (x >= 1.0) x -= 1.0;
+	return x;
+}
+
+/* single precision value of the same uniform, |error| < 1e-6: only good enough to pre-filter a
+ * decision that is re-taken in double whenever it is close (callers also re-take it near 0 and 1,
+ * where the fractional part could wrap differently) */
+ISG_HD float isg_wh_value_f32(const isg_wh *s)
+{
+	float x = (float)s->s1 * (1.0f / 30269.0f) + (float)s->s2 * (1.0f / 30307.0f) + (float)s->s3 * (1.0f / 30323.0f);
+	x = (x >= 2.0f) ? x - 2.0f : ((x >= 1.0f) ? x - 1.0f : x);
 	return x;
 }
 
