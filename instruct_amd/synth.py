@@ -154,6 +154,46 @@ def read_text_diploid(path: str, ploidy: int = 2) -> np.ndarray:
     return arr.reshape(N, ploidy, arr.shape[1]).transpose(0, 2, 1).copy()
 
 
+def write_text_polyploid(path: str, raw: np.ndarray) -> None:
+    """Reference input format for ploidy 4 (one line per individual, P adjacent tokens per locus;
+    ``data_interface.c:247-350``)."""
+    N, L, P = raw.shape
+    with open(path, "w") as f:
+        for i in range(N):
+            f.write(" ".join(str(int(v)) for v in raw[i].reshape(-1)))
+            f.write("\n")
+
+
+def code_tetraploid(raw: np.ndarray):
+    """Restates ``transform_data2`` + ``get_missing_tetra`` (data_interface.c:571-669, 722-741).
+
+    Returns (obs int32 [N][L][P]: the sorted DISTINCT allele codes of each (individual, locus), padded
+    with -1; alleleid int32 [N][L]: how many there are (0 = missing); allelenum int32 [L]).  Codes are
+    numbered per locus in order of first appearance scanning individuals, then copies; loci are not dropped.
+    """
+    N, L, P = raw.shape
+    obs = np.full((N, L, P), -1, dtype=np.int32)
+    alleleid = np.zeros((N, L), dtype=np.int32)
+    allelenum = np.zeros(L, dtype=np.int32)
+    for j in range(L):
+        col = raw[:, j, :].reshape(-1)
+        valid = col != MISSING
+        vals, first = np.unique(col[valid], return_index=True)
+        order = np.argsort(first, kind="stable")
+        rank = np.empty(vals.size, dtype=np.int32)
+        rank[order] = np.arange(vals.size, dtype=np.int32)
+        allelenum[j] = vals.size
+        coded = np.full(col.shape, -1, dtype=np.int32)
+        if vals.size:
+            coded[valid] = rank[np.searchsorted(vals, col[valid])]
+        coded = coded.reshape(N, P)
+        for i in range(N):
+            d = np.unique(coded[i][coded[i] >= 0])
+            alleleid[i, j] = d.size
+            obs[i, j, :d.size] = d
+    return obs, alleleid, allelenum
+
+
 def make_diploid(N, L, K, missing_frac=0.0, n_alleles=2, seed=20260101):
     raw = raw_alleles(N, L, K, 2, n_alleles, missing_frac, seed)
     if n_alleles == 2:

@@ -32,6 +32,19 @@ CASES = {
 }
 
 
+# ploidy 4 (autotetraploid): name: (N, L, K, n_alleles, missing, u, b, t, e, r, j, seeds)
+POLY_CASES = {
+    "t1":    (60, 40, 3, 4, 0.05, 60, 30, 5, 1, 4, 4, (13, 4, 1972)),
+    "t2_e0": (30, 30, 2, 3, 0.03, 60, 30, 5, 0, 4, 4, (14, 5, 1973)),
+    "t3_a2": (40, 50, 3, 2, 0.00, 60, 30, 5, 1, 4, 4, (15, 6, 1974)),
+}
+
+
+def poly_data_for(name):
+    N, L, K, A, miss = POLY_CASES[name][:5]
+    return synth.raw_alleles(N, L, K, 4, A, miss, 20260201 + sorted(POLY_CASES).index(name))
+
+
 def data_for(name):
     N, L, K, A, miss = CASES[name][:5]
     base = {"c1_e0": "c1", "c1_y0": "c1", "c1_mode1": "c1", "c1_c2": "c1"}.get(name, name)
@@ -49,6 +62,15 @@ def main():
         out = os.path.join(HERE, name + ".golden")
         args = [os.path.join(REF, "ref_dump"), txt, out] + [str(x) for x in
                 (K, N, L, u, b, t, c, e, y, r, j, seeds[0], seeds[1], seeds[2], mode, pf, detail)]
+        with open(os.devnull, "w") as devnull:
+            subprocess.check_call(args, stdout=devnull)
+        print(name, os.path.getsize(out), "bytes")
+    for name, cfg in POLY_CASES.items():
+        N, L, K, A, miss, u, b, t, e, r, j, seeds = cfg
+        txt = os.path.join(HERE, name + ".txt")
+        synth.write_text_polyploid(txt, poly_data_for(name))
+        out = os.path.join(HERE, name + ".golden")
+        args = [os.path.join(REF, "ref_dump_poly"), txt, out] + [str(x) for x in (K, N, L, u, b, t, e, r, j) + tuple(seeds)]
         with open(os.devnull, "w") as devnull:
             subprocess.check_call(args, stdout=devnull)
         print(name, os.path.getsize(out), "bytes")
