@@ -1,0 +1,850 @@
+/*
+ * isg_oracle_poly.c -- TEST INFRASTRUCTURE.  CPU restatement of the reference's autotetraploid sampler
+ * (poly_geno.c:75-140 with -ap 1) in its reference configuration: glibc math, sequential sums, one
+ * sequential Wichmann-Hill stream, and the reference's float/double promotion pattern for the genotype
+ * frequency tables (poly_geno.h:19-20 declares them float).  Pinned byte-for-byte to
+ * tests/golden/t*.golden, which oracle/ref_dump_poly.c generated from the real reference sweeps.
+ *
+ * NOT part of the product.  The MI355X kernels for this path are not written yet;
+ * this file and its fixtures are the parity anchor they will be built against.
+ *
+ * usage (dump tool, main() below): orc_dump_poly data.txt out K N L u b t e r j s1 s2 s3
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include "dump_fmt.h"
+
+#define MIN2(X, Y) (((X) > (Y)) ? (Y) : (X))
+#define P4 4
+
+/* ------------------------------------------------------------------ RNG + samplers (random.c) */
+static long sd1 = 13, sd2 = 4, sd3 = 1972;
+static double ran1(void)
+{
+	sd1 = (171 * sd1) % 30269;
+	sd2 = (172 * sd2) % 30307;
+	sd3 = (170 * sd3) % 30323;
+	return fmod(sd1 / 30269.0 + sd2 / 30307.0 + sd3 / 30323.0, 1.0);
+}
+#define E_CONST 2.71828182
+static double rgamma1(double alpha)
+{
+	double u0 = ran1(), u1 = ran1(), r, x;
+	if (u0 > E_CONST / (alpha + E_CONST)) {
+		r = -log((alpha + E_CONST) * (1 - u0) / (alpha * E_CONST));
+		if (u1 > pow(r, alpha - 1)) return -1;
+		return r;
+	}
+	x = (alpha + E_CONST) * u0 / E_CONST;
+	r = pow(x, 1 / alpha);
+	if (u1 > exp(-r)) return -1;
+	return r;
+}
+static double rgamma2(double alpha)
+{
+	double u1, u2, c1 = alpha - 1, c2 = (alpha - 1 / (6 * alpha)) / c1, c3 = 2 / c1, c4 = c3 + 2, c5 = 1 / sqrt(alpha), w;
+	do {
+		u1 = ran1();
+		u2 = ran1();
+		if (alpha > 2.5) u1 = u2 + c5 * (1 - 1.86 * u1);
+	} while ((u1 >= 1) || (u1 <= 0));
+	w = c2 * u2 / u1;
+	if ((c3 * u1 + w + 1 / w) > c4)
+		if ((c3 * log(u1) - log(w) + w) >= 1) return -1;
+	return c1 * w;
+}
+static double rgamma(double alpha)
+{
+	double r = 0;
+	if (alpha < 1) do { r = rgamma1(alpha); } while (r < 0);
+	if (alpha == 1) r = -(1 / 1.0) * log(ran1());
+	if (alpha > 1) do { r = rgamma2(alpha); } while (r < 0);
+	return r;
+}
+static void rdirich(const double *alpha, int n, double *out, double add)
+{
+	double sum = 0;
+	int k;
+	for (k = 0; k < n; k++) { out[k] = rgamma(alpha[k] + add); sum += out[k]; }
+	for (k = 0; k < n; k++) out[k] /= sum;
+}
+static int disc_unif(double *vec, int length) /* random.c:403-430 */
+{
+	int i, flag = 0;
+	double x = ran1();
+	for (i = 0; i < length; i++) vec[i] /= vec[length - 1];
+	if (x <= vec[0] && x >= 0.00) flag = 0;
+	else
+		for (i = 1; i < length; i++)
+			if (x > vec[i - 1] && x <= vec[i]) flag = i;
+	return flag;
+}
+
+/* ------------------------------------------------------------------ problem + state */
+static int N, L, K, Amax, back_refl;
+static int *allelenum, *obs, *alleleid;    /* obs [N][L][4] sorted distinct codes, alleleid [N][L] */
+static int *z, *geno, *state;              /* [N][L][4] */
+static double *freq, *qq, *qqnum, *S, *indvlkh, alpha, totallkh;
+/* POLY (poly_geno.h:10-21) */
+static int num_allele, *allele_poly, (*genonum)[6], **genolist;
+static float **exfreq, **genofreq;         /* [K*L] -> float[G] */
+static int err_flag;
+
+#define OBS(i, j, k) obs[((long)(i) * L + (j)) * P4 + (k)]
+#define Z(i, j, k) z[((long)(i) * L + (j)) * P4 + (k)]
+#define GENO(i, j, k) geno[((long)(i) * L + (j)) * P4 + (k)]
+#define FREQ(k, j, a) freq[((long)(k) * L + (j)) * Amax + (a)]
+#define VALID(i, j) (alleleid[(long)(i) * L + (j)] != 0)
+
+static int exists(int value, const int *vec, int leng) /* data_interface.c:865-877 */
+{
+	int i, flag = 0;
+	for (i = 0; i < leng; i++) if (value == vec[i]) flag = 1;
+	return flag;
+}
+static int find_id(int num, const int *array, int len) /* poly_geno.c:2367-2381 */
+{
+	int i;
+	for (i = 0; i < len; i++) if (array[i] == num) return i;
+	err_flag = 1;
+	return 0;
+}
+static int chcksame(const int *p, int n) { int i, f = 0; for (i = 1; i < n; i++) if (p[i] != p[0]) f = 1; return f; }
+static int nid_of(int j) { return find_id(allelenum[j], allele_poly, num_allele); }
+static int gtot(int j) { return genonum[nid_of(j)][0]; }
+
+static void gen_polyinfo(void) /* poly_geno.c:143-184, 1673-1800 */
+{
+	int i, j, k, m, n, l, cnt, tmp, *t = malloc(sizeof(int) * (L + 1));
+	cnt = 0;
+	for (i = 0; i < L; i++) if (!exists(allelenum[i], t, cnt)) t[cnt++] = allelenum[i];
+	for (i = 0; i < cnt - 1; i++) for (j = i + 1; j < cnt; j++) if (t[i] > t[j]) { tmp = t[i]; t[i] = t[j]; t[j] = tmp; }
+	num_allele = cnt;
+	allele_poly = t;
+	genonum = malloc(sizeof(*genonum) * cnt);
+	genolist = malloc(sizeof(int *) * cnt);
+	for (l = 0; l < cnt; l++) {
+		i = allele_poly[l];
+		genonum[l][1] = i;
+		genonum[l][2] = i * (i - 1);
+		genonum[l][3] = i * (i - 1) / 2;
+		genonum[l][4] = i * (i - 1) * (i - 2) / 2;
+		genonum[l][5] = i * (i - 1) * (i - 2) * (i - 3) / 24;
+		genonum[l][0] = i + i * (i - 1) * 3 / 2 + i * (i - 1) * (i - 2) / 2 + i * (i - 1) * (i - 2) * (i - 3) / 24;
+		genolist[l] = malloc(sizeof(int) * (genonum[l][0] + 1));
+		for (j = 0; j < genonum[l][1]; j++) genolist[l][j] = j * (i * i * i + i * i + i + 1);
+		tmp = genonum[l][1];
+		cnt = 0;
+		for (j = 0; j < i - 1; j++)
+			for (k = j + 1; k < i; k++) {
+				genolist[l][tmp + 2 * cnt] = j * (i * i * i + i * i + i) + k;
+				genolist[l][tmp + 2 * cnt + 1] = i * (i * i + i + 1) * k + j;
+				cnt++;
+			}
+		tmp += genonum[l][2];
+		cnt = 0;
+		for (j = 0; j < i - 1; j++)
+			for (k = j + 1; k < i; k++) genolist[l][tmp + cnt++] = j * (i * i * i + i * i) + k * (i + 1);
+		tmp += genonum[l][3];
+		cnt = 0;
+		for (j = 0; j < i - 2; j++)
+			for (k = j + 1; k < i - 1; k++)
+				for (m = k + 1; m < i; m++) {
+					genolist[l][tmp + 3 * cnt] = j * (i * i * i + i * i) + k * i + m;
+					genolist[l][tmp + 3 * cnt + 1] = k * (i * i * i + i * i) + j * i + m;
+					genolist[l][tmp + 3 * cnt + 2] = m * (i * i * i + i * i) + j * i + k;
+					cnt++;
+				}
+		tmp += genonum[l][4];
+		cnt = 0;
+		for (j = 0; j < i - 3; j++)
+			for (k = j + 1; k < i - 2; k++)
+				for (m = k + 1; m < i - 1; m++)
+					for (n = m + 1; n < i; n++) genolist[l][tmp + cnt++] = j * i * i * i + k * i * i + i * m + n;
+	}
+	exfreq = malloc(sizeof(float *) * K * L);
+	genofreq = malloc(sizeof(float *) * K * L);
+	for (k = 0; k < K; k++)
+		for (j = 0; j < L; j++) {
+			exfreq[k * L + j] = calloc(gtot(j), sizeof(float));
+			genofreq[k * L + j] = calloc(gtot(j), sizeof(float));
+		}
+}
+
+static void set_geno(int i, int j, int a, int b, int c, int d) { GENO(i, j, 0) = a; GENO(i, j, 1) = b; GENO(i, j, 2) = c; GENO(i, j, 3) = d; }
+static void two_allele_auto(int num, int i, int j) /* poly_geno.c:2440-2464 */
+{
+	int a = OBS(i, j, 0), b = OBS(i, j, 1);
+	if (num == 1) set_geno(i, j, a, a, a, b);
+	else if (num == 2) set_geno(i, j, b, b, b, a);
+	else if (num == 3) set_geno(i, j, a, a, b, b);
+}
+static void tri_allele_auto(int num, int i, int j) /* poly_geno.c:2509-2530 */
+{
+	int a = OBS(i, j, 0), b = OBS(i, j, 1), c = OBS(i, j, 2);
+	if (num == 1) set_geno(i, j, a, a, b, c);
+	else if (num == 2) set_geno(i, j, b, b, a, c);
+	else if (num == 3) set_geno(i, j, c, c, a, b);
+}
+static int choose_unif(int temp) /* poly_geno.c:840-852 */
+{
+	double tmp[8];
+	int j;
+	for (j = 0; j < temp; j++) tmp[j] = (double)(j + 1) / (double)temp;
+	return disc_unif(tmp, temp) + 1;
+}
+static void initial_geno(void) /* poly_geno.c:316-369 (autopoly) */
+{
+	int i, j, k;
+	for (i = 0; i < N; i++)
+		for (j = 0; j < L; j++) {
+			if (!VALID(i, j)) continue;
+			switch (alleleid[(long)i * L + j]) {
+			case 1: for (k = 0; k < P4; k++) GENO(i, j, k) = OBS(i, j, 0); break;
+			case 2: two_allele_auto(choose_unif(3), i, j); break;
+			case 3: tri_allele_auto(choose_unif(3), i, j); break;
+			case 4: for (k = 0; k < P4; k++) GENO(i, j, k) = OBS(i, j, k); break;
+			}
+		}
+}
+
+static void update_P_auto(void) /* poly_geno.c:390-438 */
+{
+	int *cnt = calloc((size_t)K * L * Amax, sizeof(int));
+	double *tmp = malloc(sizeof(double) * Amax);
+	int i, j, k;
+	for (i = 0; i < N; i++)
+		for (j = 0; j < L; j++)
+			if (VALID(i, j))
+				for (k = 0; k < P4; k++) cnt[((long)Z(i, j, k) * L + j) * Amax + GENO(i, j, k)]++;
+	for (i = 0; i < K; i++)
+		for (j = 0; j < L; j++) {
+			for (k = 0; k < allelenum[j]; k++) tmp[k] = (double)cnt[((long)i * L + j) * Amax + k];
+			rdirich(tmp, allelenum[j], &FREQ(i, j, 0), 1.0);
+		}
+	free(cnt);
+	free(tmp);
+}
+
+static void calc_exfreq_auto(void) /* poly_geno.c:1515-1590 */
+{
+	int i, j, k, m, n, digit[4], id, temp, tmp;
+	for (k = 0; k < K; k++)
+		for (i = 0; i < L; i++) {
+			float *ex = exfreq[k * L + i];
+			n = allelenum[i];
+			id = nid_of(i);
+			for (j = 0; j < genonum[id][1]; j++) {
+				tmp = genolist[id][j];
+				digit[0] = tmp % n;
+				ex[j] = (float)log(FREQ(k, i, digit[0])) * (float)P4;
+			}
+			temp = genonum[id][1];
+			for (j = temp; j < temp + genonum[id][2]; j++) {
+				tmp = genolist[id][j];
+				digit[0] = tmp % n;
+				tmp /= n;
+				digit[1] = tmp % n;
+				ex[j] = (float)(log(4.0) + log(FREQ(k, i, digit[1])) * (float)(P4 - 1) + log(FREQ(k, i, digit[0])));
+			}
+			temp += genonum[id][2];
+			for (j = temp; j < temp + genonum[id][3]; j++) {
+				tmp = genolist[id][j];
+				digit[0] = tmp % n;
+				tmp /= (n * n);
+				digit[1] = tmp % n;
+				ex[j] = (float)(log(6.0) + (log(FREQ(k, i, digit[1])) + log(FREQ(k, i, digit[0]))) * (P4 / 2));
+			}
+			temp += genonum[id][3];
+			for (j = temp; j < temp + genonum[id][4]; j++) {
+				tmp = genolist[id][j];
+				for (m = 0; m < P4 - 1; m++) { digit[m] = tmp % n; tmp /= n; }
+				ex[j] = (float)(log(12.0) + log(FREQ(k, i, digit[2])) * (P4 / 2) + log(FREQ(k, i, digit[0])) + log(FREQ(k, i, digit[1])));
+			}
+			temp += genonum[id][4];
+			for (j = temp; j < temp + genonum[id][5]; j++) {
+				tmp = genolist[id][j];
+				for (m = 0; m < P4; m++) { digit[m] = tmp % n; tmp /= n; }
+				ex[j] = (float)log(24.0);
+				for (m = 0; m < P4; m++) ex[j] += (float)log(FREQ(k, i, digit[m]));
+			}
+		}
+}
+
+static int calc_val(const int *num, int val, int i) /* poly_geno.c:2305-2330 */
+{
+	int temp = 0;
+	if (val < num[0]) temp = val * i * i * i + num[0] * i * i + num[1] * i + num[2];
+	else if (val > num[0] && val < num[1]) temp = num[0] * i * i * i + val * i * i + num[1] * i + num[2];
+	else if (val > num[1] && val < num[2]) temp = num[0] * i * i * i + num[1] * i * i + val * i + num[2];
+	else if (val > num[2]) temp = num[0] * i * i * i + num[1] * i * i + num[2] * i + val;
+	return temp;
+}
+static int calc_val2(const int *num, int val1, int val2, int i) /* poly_geno.c:2332-2365 */
+{
+	int temp = 0;
+	if (val2 < num[1]) temp = val1 * i * i * i + val2 * i * i + num[1] * i + num[0];
+	else if (val2 > num[1] && val2 < num[0] && val1 < num[1]) temp = val1 * i * i * i + num[1] * i * i + val2 * i + num[0];
+	else if (val1 > num[1] && val2 < num[0]) temp = num[1] * i * i * i + val1 * i * i + val2 * i + num[0];
+	else if (val1 > num[1] && val1 < num[0] && val2 > num[0]) temp = num[1] * i * i * i + val1 * i * i + num[0] * i + val2;
+	else if (val1 > num[0]) temp = num[1] * i * i * i + num[0] * i * i + val1 * i + val2;
+	else if (val1 < num[1] && val2 > num[0]) temp = val1 * i * i * i + num[1] * i * i + i * num[0] + val2;
+	return temp;
+}
+
+static void gaussj3(float a[4][4], float b[4]) /* poly_geno.c:2384-2435 with n = 3, m = 1 (1-based) */
+{
+	int indxc[4], indxr[4], ipiv[4], i, icol = 1, irow = 1, j, k, l, ll, n = 3;
+	float big, dum, pivinv, temp;
+	for (j = 1; j <= n; j++) ipiv[j] = 0;
+	for (i = 1; i <= n; i++) {
+		big = 0.0;
+		for (j = 1; j <= n; j++)
+			if (ipiv[j] != 1)
+				for (k = 1; k <= n; k++)
+					if (ipiv[k] == 0)
+						if (fabs(a[j][k]) >= big) { big = fabs(a[j][k]); irow = j; icol = k; }
+		++(ipiv[icol]);
+		if (irow != icol) {
+			for (l = 1; l <= n; l++) { temp = a[irow][l]; a[irow][l] = a[icol][l]; a[icol][l] = temp; }
+			temp = b[irow]; b[irow] = b[icol]; b[icol] = temp;
+		}
+		indxr[i] = irow;
+		indxc[i] = icol;
+		if (a[icol][icol] == 0.0) { err_flag = 2; return; }
+		pivinv = 1.0 / a[icol][icol];
+		a[icol][icol] = 1.0;
+		for (l = 1; l <= n; l++) a[icol][l] *= pivinv;
+		b[icol] *= pivinv;
+		for (ll = 1; ll <= n; ll++)
+			if (ll != icol) {
+				dum = a[ll][icol];
+				a[ll][icol] = 0.0;
+				for (l = 1; l <= n; l++) a[ll][l] -= a[icol][l] * dum;
+				b[ll] -= b[icol] * dum;
+			}
+	}
+	for (l = n; l >= 1; l--)
+		if (indxr[l] != indxc[l])
+			for (k = 1; k <= n; k++) { temp = a[k][indxr[l]]; a[k][indxr[l]] = a[k][indxc[l]]; a[k][indxc[l]] = temp; }
+}
+
+/* auto_genfreq (poly_geno.c:1803-2028): log genotype frequencies under selfing rate `self` for cluster
+ * pop_id at locus loci_id, solved class by class from quadri-allelic down to mono-allelic genotypes */
+static void auto_genfreq(float self, int pop_id, int loci_id, float *fr)
+{
+	int i, j, k, l, n = allelenum[loci_id], id = nid_of(loci_id), tmp, digit[3], num = 0, tri = 3;
+	const int *gl = genolist[id];
+	const int G = genonum[id][0];
+	const float *ex = exfreq[pop_id * L + loci_id];
+	float temp, matr[4][4], vec[4];
+	tmp = G;
+	if (n >= 4)
+		for (i = tmp - genonum[id][5]; i < tmp; i++) {
+			fr[i] = log(1 - self) + ex[i] - log(1 - self / 6);
+			if (fr[i] > 0) err_flag = 3;
+		}
+	if (n >= 3) {
+		tmp -= genonum[id][5];
+		for (i = 0; i < genonum[id][4] / tri; i++) {
+			num = gl[tmp - genonum[id][4] + i * 3];
+			for (j = P4 - 2; j >= 0; j--) { digit[j] = num % n; num /= n; }
+			temp = 0;
+			if (n >= 4) {
+				for (l = 0; l < n; l++)
+					if (exists(l, digit, tri) == 0) {
+						num = find_id(calc_val(digit, l, n), gl, G);
+						temp += exp(fr[num]);
+					}
+				if (temp > 1) err_flag = 3;
+			}
+			for (j = 1; j <= tri; j++) {
+				for (k = 1; k <= tri; k++) {
+					if (j == k) matr[j][k] = 1 - self * 10.0 / 36.0;
+					else matr[j][k] = -self / 9.0;
+				}
+				vec[j] = self / 18.0 * temp + (1.0 - self) * exp(ex[tmp - genonum[id][4] + i * 3 + j - 1]);
+			}
+			temp = vec[1];
+			for (j = 1; j <= tri; j++) vec[j] /= temp;
+			gaussj3(matr, vec);
+			for (j = 0; j < tri; j++) {
+				fr[tmp - genonum[id][4] + i * 3 + j] = log(vec[j + 1]) + log(temp);
+				if (fr[tmp - genonum[id][4] + i * 3 + j] > 0) err_flag = 3;
+			}
+		}
+	}
+	tmp -= genonum[id][4];
+	for (i = tmp - genonum[id][3]; i < tmp; i++) { /* duplex iijj */
+		num = gl[i];
+		digit[0] = num % n;
+		num /= (n * n);
+		digit[1] = num % n;
+		temp = 0;
+		if (n >= 3)
+			for (j = 0; j < n; j++)
+				if (exists(j, digit, 2) == 0) {
+					if (digit[0] < j) num = find_id(digit[1] * n * n * (n + 1) + digit[0] * n + j, gl, G);
+					else if (digit[0] > j) num = find_id(digit[1] * n * n * (n + 1) + j * n + digit[0], gl, G);
+					temp += exp(fr[num]) / 9.0 * self;
+					if (digit[1] < j) num = find_id(digit[0] * n * n * (n + 1) + digit[1] * n + j, gl, G);
+					else if (digit[1] > j) num = find_id(digit[0] * n * n * (n + 1) + j * n + digit[1], gl, G);
+					temp += exp(fr[num]) / 9.0 * self;
+					num = find_id(j * n * n * (n + 1) + digit[1] * n + digit[0], gl, G);
+					temp += exp(fr[num]) / 36.0 * self;
+					if (n >= 4)
+						for (k = j + 1; k < n; k++)
+							if (exists(k, digit, 2) == 0) {
+								num = find_id(calc_val2(digit, j, k, n), gl, G);
+								temp += exp(fr[num]) / 36.0 * self;
+							}
+				}
+		fr[i] = log((1 - self) * exp(ex[i]) + temp) - log(1 - self / 2.0);
+		if (fr[i] > 0) err_flag = 3;
+	}
+	tmp -= genonum[id][3];
+	for (i = tmp - genonum[id][2]; i < tmp; i++) { /* simplex iiij */
+		num = gl[i];
+		digit[0] = num % n;
+		num /= n;
+		digit[1] = num % n;
+		if (digit[0] < digit[1]) num = find_id((digit[0] * n * n + digit[1]) * (n + 1), gl, G);
+		else if (digit[0] > digit[1]) num = find_id((digit[1] * n * n + digit[0]) * (n + 1), gl, G);
+		temp = 8.0 / 36.0 * exp(fr[num]) * self;
+		if (n >= 3)
+			for (j = 0; j < n; j++)
+				if (exists(j, digit, 2) == 0) {
+					if (digit[0] < j) num = find_id(digit[1] * n * n * (n + 1) + digit[0] * n + j, gl, G);
+					else if (digit[0] > j) num = find_id(digit[1] * n * n * (n + 1) + j * n + digit[0], gl, G);
+					temp += exp(fr[num]) / 9.0 * self;
+				}
+		fr[i] = log((1 - self) * exp(ex[i]) + temp) - log(1 - self / 2.0);
+		if (fr[i] > 0) err_flag = 3;
+	}
+	tmp -= genonum[id][2];
+	for (i = tmp - genonum[id][1]; i < tmp; i++) { /* mono iiii */
+		num = gl[i];
+		digit[0] = num % n;
+		temp = 0;
+		for (j = 0; j < n; j++)
+			if (j != digit[0]) {
+				num = find_id(digit[0] * n * (n * n + n + 1) + j, gl, G);
+				temp += exp(fr[num]) / 4.0 * self;
+				/* sic: when digit[0] > j the reference's second branch repeats the first test, so the
+				 * duplex term reuses the simplex index found above (poly_geno.c:1990-1996) */
+				if (digit[0] < j) num = find_id(digit[0] * n * n * (n + 1) + j * (n + 1), gl, G);
+				temp += exp(fr[num]) / 36.0 * self;
+				if (n >= 3)
+					for (k = j + 1; k < n; k++)
+						if (k != digit[0]) {
+							num = find_id(digit[0] * n * n * (n + 1) + j * n + k, gl, G);
+							temp += exp(fr[num]) / 36.0 * self;
+						}
+			}
+		fr[i] = log((1 - self) * exp(ex[i]) + temp) - log(1 - self);
+		if (fr[i] > 0) err_flag = 3;
+	}
+}
+static void calc_self_genofreq(double self_rate, float **tab, int k, int own) /* poly_geno.c:1219-1233 */
+{
+	int i;
+	for (i = 0; i < L; i++) auto_genfreq((float)self_rate, k, i, own ? tab[k * L + i] : tab[i]);
+}
+
+static int copy_num(int val, const int *vec, int leng) { int i, n = 0; for (i = 0; i < leng; i++) if (val == vec[i]) n++; return n; }
+static int get_cat_auto(const int *g) /* poly_geno.c:1313-1339 */
+{
+	int i, cnt = 0, tmp[4];
+	tmp[cnt++] = g[0];
+	for (i = 1; i < P4; i++) if (!exists(g[i], tmp, cnt)) tmp[cnt++] = g[i];
+	switch (cnt) {
+	case 1: return 0;
+	case 2: return copy_num(tmp[0], g, P4) == 2 ? 2 : 1;
+	case 3: return 3;
+	default: return 4;
+	}
+}
+static int get_index_auto(int j, const int *g, int *cat) /* poly_geno.c:1289-1311 */
+{
+	int i, temp = g[0], id = nid_of(j);
+	*cat = get_cat_auto(g);
+	for (i = 1; i < P4; i++) temp = temp * allelenum[j] + g[i];
+	return find_id(temp, genolist[id], genonum[id][0]);
+}
+static double calc_genofq(int j, int i, const int *zz) /* poly_geno.c:1235-1286 */
+{
+	int cat, m, gid;
+	double ld = 0;
+	if (!VALID(i, j)) return 0;
+	gid = get_index_auto(j, &GENO(i, j, 0), &cat);
+	if (chcksame(zz, P4) == 0) return (double)genofreq[zz[0] * L + j][gid];
+	for (m = 0; m < P4; m++) ld += log(FREQ(zz[m], j, GENO(i, j, m)));
+	switch (cat) {
+	case 1: ld += log(4); break;
+	case 2: ld += log(6); break;
+	case 3: ld += log(12); break;
+	case 4: ld += log(24); break;
+	}
+	return ld;
+}
+static double cal_lkd(void) /* poly_geno.c:715-735 */
+{
+	int i, j;
+	double ld, sum = 0;
+	for (i = 0; i < N; i++) {
+		ld = 0;
+		for (j = 0; j < L; j++) if (VALID(i, j)) ld += calc_genofq(j, i, &Z(i, j, 0));
+		indvlkh[i] = ld;
+		sum += ld;
+	}
+	return sum;
+}
+static double cal_lkd_props(int id, float **tab) /* poly_geno.c:645-711 */
+{
+	int i, j, m, cat, gid;
+	double ld = 0;
+	for (i = 0; i < N; i++)
+		for (j = 0; j < L; j++) {
+			if (!VALID(i, j)) continue;
+			gid = get_index_auto(j, &GENO(i, j, 0), &cat);
+			if (chcksame(&Z(i, j, 0), P4) == 0) {
+				if (id == Z(i, j, 0)) ld += (double)tab[j][gid];
+				else ld += (double)genofreq[Z(i, j, 0) * L + j][gid];
+			} else {
+				for (m = 0; m < P4; m++) ld += log(FREQ(Z(i, j, m), j, GENO(i, j, m)));
+				switch (cat) {
+				case 1: ld += log(4); break;
+				case 2: ld += log(6); break;
+				case 3: ld += log(12); break;
+				case 4: ld += log(24); break;
+				}
+			}
+		}
+	return ld;
+}
+
+static int dt_stat(double num)
+{
+	double eps = 0.001;
+	if (num <= 0.000 + eps && num >= 0.000 - eps) return 0;
+	if (num >= 1.000 - eps && num <= 1.000 + eps) return 2;
+	if (num >= 0.0 + eps && num < 1.000 - eps) return 1;
+	err_flag = 4;
+	return 1;
+}
+static double adpt_indp(int *stat_tmp, int stat)
+{
+	double tmp = 0, tt;
+	if (stat == 0) { if (ran1() < 0.50) { tmp = 0; *stat_tmp = 0; } else { tmp = ran1(); *stat_tmp = 1; } }
+	else if (stat == 2) { if (ran1() < 0.5) { tmp = 1; *stat_tmp = 2; } else { tmp = ran1(); *stat_tmp = 1; } }
+	else { tt = ran1(); if (tt <= 0.05) { tmp = 0; *stat_tmp = 0; } else if (tt >= 0.95) { tmp = 1; *stat_tmp = 2; } else { tmp = ran1(); *stat_tmp = 1; } }
+	return tmp;
+}
+static double q_trans(int a, int b)
+{
+	if (a == 0) return (b == 0 || b == 1) ? 0.5 : 0.0;
+	if (a == 2) return (b == 2 || b == 1) ? 0.5 : 0.0;
+	if (a == 1) return (b == 0 || b == 2) ? 0.05 : (b == 1 ? 0.90 : 0.0);
+	return 0.0;
+}
+
+static void update_S_POP(void) /* poly_geno.c:584-643 */
+{
+	int i, j, *tem_stat = malloc(sizeof(int) * K);
+	double delta0 = 0.05, mhratio, tmp = 0;
+	float **tab = malloc(sizeof(float *) * L);
+	for (i = 0; i < L; i++) tab[i] = malloc(sizeof(float) * gtot(i));
+	for (j = 0; j < K; j++) calc_self_genofreq(S[j], genofreq, j, 1);
+	for (j = 0; j < K; j++) {
+		if (back_refl == 1) {
+			tmp = ran1() * 2 * delta0 - delta0;
+			tmp += S[j];
+			if (tmp <= 0.000) tmp = 0.000 - tmp;
+			else if (tmp >= 1.000) tmp = 1.000 - (tmp - 1.000);
+		} else {
+			for (i = 0; i < K; i++) tem_stat[i] = state[i];
+			tmp = adpt_indp(tem_stat + j, state[j]);
+		}
+		calc_self_genofreq(tmp, tab, j, 0);
+		mhratio = cal_lkd_props(j, tab) - cal_lkd();
+		if (back_refl == 0) {
+			double h = 1.0;
+			for (i = 0; i < K; i++) h *= q_trans(state[i], tem_stat[i]) / q_trans(tem_stat[i], state[i]);
+			mhratio *= h; /* sic: the Hastings factor multiplies the LOG ratio (poly_geno.c:622-623) */
+		}
+		if (ran1() < exp(MIN2(0, mhratio))) {
+			S[j] = tmp;
+			if (back_refl == 0) state[j] = tem_stat[j];
+			for (i = 0; i < L; i++) memcpy(genofreq[j * L + i], tab[i], sizeof(float) * gtot(i));
+		}
+	}
+	for (i = 0; i < L; i++) free(tab[i]);
+	free(tab);
+	free(tem_stat);
+}
+
+static void update_ZQ(int init_flag) /* poly_geno.c:750-836 */
+{
+	int i, j, k, m;
+	double *tmp = malloc(sizeof(double) * K);
+	for (i = 0; i < N; i++) {
+		for (j = 0; j < L; j++)
+			if (VALID(i, j))
+				for (k = 0; k < P4; k++) {
+					for (m = 0; m < K; m++) {
+						if (init_flag == 1) tmp[m] = (double)(m + 1) / K;
+						else {
+							tmp[m] = qq[(long)i * K + m] * FREQ(m, j, GENO(i, j, k));
+							if (m >= 1) tmp[m] += tmp[m - 1];
+						}
+					}
+					Z(i, j, k) = disc_unif(tmp, K);
+				}
+		for (m = 0; m < K; m++) qqnum[(long)i * K + m] = 0.0;
+		for (j = 0; j < L; j++)
+			if (VALID(i, j))
+				for (k = 0; k < P4; k++) qqnum[(long)i * K + Z(i, j, k)] += 1.0;
+		for (k = 0; k < K; k++) tmp[k] = qqnum[(long)i * K + k];
+		rdirich(tmp, K, &qq[(long)i * K], alpha);
+	}
+	free(tmp);
+}
+
+static int choose_auto(int i, int j, int n_type) /* choose_two_auto / choose_tri_auto, poly_geno.c:854-960 */
+{
+	int a, b, num[3], id[3], n = allelenum[j], nid = nid_of(j);
+	double tmp[3], fq[3], tm;
+	for (a = 0; a < n_type; a++) id[a] = OBS(i, j, a);
+	if (chcksame(&Z(i, j, 0), P4) == 0) {
+		if (n_type == 2) {
+			num[0] = id[0] * n * (n * n + n + 1) + id[1];
+			num[1] = id[1] * n * (n * n + n + 1) + id[0];
+			num[2] = (id[0] * n * n + id[1]) * (n + 1);
+		} else {
+			num[0] = id[0] * n * n * (n + 1) + id[1] * n + id[2];
+			num[1] = id[1] * n * n * (n + 1) + id[0] * n + id[2];
+			num[2] = id[2] * n * n * (n + 1) + id[0] * n + id[1];
+		}
+		for (a = 0; a < 3; a++) tmp[a] = (double)genofreq[Z(i, j, 0) * L + j][find_id(num[a], genolist[nid], genonum[nid][0])];
+	} else {
+		for (a = 0; a < n_type; a++) {
+			fq[a] = 0;
+			for (b = 0; b < K; b++) fq[a] += qq[(long)i * K + b] * FREQ(b, j, id[a]);
+		}
+		if (n_type == 2) {
+			tmp[0] = log(4) + 3 * log(fq[0]) + log(fq[1]);
+			tmp[1] = log(4) + 3 * log(fq[1]) + log(fq[0]);
+			tmp[2] = log(6) + 2 * log(fq[0]) + 2 * log(fq[1]);
+		} else {
+			tmp[0] = 2 * log(fq[0]) + log(fq[1]) + log(fq[2]);
+			tmp[1] = 2 * log(fq[1]) + log(fq[0]) + log(fq[2]);
+			tmp[2] = 2 * log(fq[2]) + log(fq[1]) + log(fq[0]);
+		}
+	}
+	tm = tmp[0];
+	for (a = 0; a < 3; a++) tmp[a] = exp(tmp[a] - tm);
+	for (a = 1; a < 3; a++) tmp[a] += tmp[a - 1];
+	return disc_unif(tmp, 3) + 1;
+}
+static void update_geno(void) /* poly_geno.c:520-580 (autopoly); the canonical-order fix-up never fires for -ap 1 */
+{
+	int i, j, k;
+	for (i = 0; i < N; i++)
+		for (j = 0; j < L; j++) {
+			if (!VALID(i, j)) continue;
+			switch (alleleid[(long)i * L + j]) {
+			case 1: for (k = 0; k < P4; k++) GENO(i, j, k) = OBS(i, j, 0); break;
+			case 2: two_allele_auto(choose_auto(i, j, 2), i, j); break;
+			case 3: tri_allele_auto(choose_auto(i, j, 3), i, j); break;
+			case 4: for (k = 0; k < P4; k++) GENO(i, j, k) = OBS(i, j, k); break;
+			}
+		}
+}
+
+/* ------------------------------------------------------------------ reader: transform_data2 (data_interface.c:571-669) */
+static int read_poly(const char *path)
+{
+	FILE *f = fopen(path, "r");
+	char *line = NULL, **tok = NULL;
+	size_t cap = 0;
+	long nrows = 0, ntok = 0, T = -1, captok = 0, i, j, k;
+	if (!f) return -1;
+	while (getline(&line, &cap, f) > 0) {
+		char *s = line;
+		long cnt = 0;
+		while (*s) {
+			while (isspace((unsigned char)*s)) s++;
+			if (!*s) break;
+			{
+				char *b = s;
+				while (*s && !isspace((unsigned char)*s)) s++;
+				if (ntok == captok) { captok = captok ? captok * 2 : 4096; tok = realloc(tok, sizeof(char *) * captok); }
+				tok[ntok++] = strndup(b, (size_t)(s - b));
+				cnt++;
+			}
+		}
+		if (cnt == 0) continue;
+		if (T < 0) T = cnt;
+		nrows++;
+	}
+	fclose(f);
+	N = (int)nrows;
+	L = (int)(T / P4);
+	allelenum = calloc(L, sizeof(int));
+	obs = malloc(sizeof(int) * (size_t)N * L * P4);
+	alleleid = calloc((size_t)N * L, sizeof(int));
+	for (i = 0; i < (long)N * L * P4; i++) obs[i] = -1;
+	for (j = 0; j < L; j++) {
+		char **types = malloc(sizeof(char *) * (size_t)N * P4);
+		int cnt = 0, m;
+		for (i = 0; i < N; i++)
+			for (k = 0; k < P4; k++) {
+				const char *t = tok[i * T + j * P4 + k];
+				if (strcmp(t, "-9") == 0) continue;
+				for (m = 0; m < cnt; m++) if (strcmp(types[m], t) == 0) break;
+				if (m == cnt) types[cnt++] = (char *)t;
+			}
+		allelenum[j] = cnt;
+		for (i = 0; i < N; i++) {
+			int flag = 0, a, b;
+			for (k = 0; k < P4; k++) {
+				const char *t = tok[i * T + j * P4 + k];
+				if (strcmp(t, "-9") == 0) continue;
+				for (m = 0; m < cnt; m++)
+					if (strcmp(t, types[m]) == 0 && !exists(m, &OBS(i, j, 0), flag)) OBS(i, j, flag++) = m;
+			}
+			for (a = 0; a < flag - 1; a++)
+				for (b = a + 1; b < flag; b++)
+					if (OBS(i, j, a) > OBS(i, j, b)) { int t2 = OBS(i, j, a); OBS(i, j, a) = OBS(i, j, b); OBS(i, j, b) = t2; }
+			alleleid[i * L + j] = flag;
+		}
+		free(types);
+	}
+	Amax = 0;
+	for (j = 0; j < L; j++) if (allelenum[j] > Amax) Amax = allelenum[j];
+	return 0;
+}
+
+/* ------------------------------------------------------------------ dump tool */
+static uint64_t hash_tables(float **tab)
+{
+	uint64_t h = fnv_init();
+	int k, j, g;
+	for (k = 0; k < K; k++)
+		for (j = 0; j < L; j++)
+			for (g = 0; g < gtot(j); g++) h = fnv_bytes(h, &tab[k * L + j][g], 4);
+	return h;
+}
+int main(int argc, char **argv)
+{
+	FILE *G;
+	dump_dims D;
+	int *vflat, *gflat, *cflat, e, r, jj, s1, s2, s3, t, i, j, k;
+	long u, b, step, cnt_step = 0;
+	float *initd;
+	double *convg;
+	/* CHAIN running means (store_chn, mcmc.c:1320-1456) */
+	double c_tot = 1, c_tot2 = 1, *c_indv, *c_S, *c_qq;
+	long c_step = 0, steps;
+	int flag_empty = 0;
+	if (argc != 15) { fprintf(stderr, "usage: orc_dump_poly data out K N L u b t e r j s1 s2 s3\n"); return 2; }
+	K = atoi(argv[3]); u = atol(argv[6]); b = atol(argv[7]); t = atoi(argv[8]); e = atoi(argv[9]); r = atoi(argv[10]); jj = atoi(argv[11]);
+	s1 = atoi(argv[12]); s2 = atoi(argv[13]); s3 = atoi(argv[14]);
+	back_refl = e;
+	if ((G = fopen(argv[2], "w")) == NULL || read_poly(argv[1])) return 2;
+	sd1 = s1; sd2 = s2; sd3 = s3;
+	initd = malloc(sizeof(float) * K);
+	for (i = 0; i < K; i++) initd[i] = (float)ran1();
+	z = calloc((size_t)N * L * P4, sizeof(int)); geno = calloc((size_t)N * L * P4, sizeof(int)); state = calloc(K, sizeof(int));
+	freq = calloc((size_t)K * L * Amax, sizeof(double)); qq = calloc((size_t)N * K, sizeof(double)); qqnum = calloc((size_t)N * K, sizeof(double));
+	S = calloc(K, sizeof(double)); indvlkh = calloc(N, sizeof(double));
+	vflat = malloc(sizeof(int) * N * L); gflat = malloc(sizeof(int) * N * L * P4); cflat = malloc(sizeof(int) * K * L * Amax);
+	for (i = 0; i < N; i++) for (j = 0; j < L; j++) vflat[i * L + j] = VALID(i, j);
+	D.N = N; D.L = L; D.P = P4; D.K = K; D.Amax = Amax; D.allelenum = allelenum; D.valid = vflat;
+	fprintf(G, "# instruct golden v1 ploidy 4 (generated by oracle/ref_dump_poly.c from the reference sweeps)\n");
+	fprintf(G, "cfg N=%d L=%d K=%d P=4 Amax=%d e=%d u=%ld b=%ld t=%d r=%d j=%d s=%d,%d,%d\n", N, L, K, Amax, e, u, b, t, r, jj, s1, s2, s3);
+	{
+		uint64_t h = fnv_init();
+		for (i = 0; i < N; i++) for (j = 0; j < L; j++) for (k = 0; k < P4; k++) h = fnv_i32(h, k < alleleid[i * L + j] ? OBS(i, j, k) : -1);
+		fprintf(G, "data hobs=%016llx halleleid=%016llx hallelenum=%016llx\n", (unsigned long long)h,
+			(unsigned long long)hash_i32v(alleleid, (long)N * L), (unsigned long long)hash_i32v(allelenum, L));
+	}
+	fprintf(G, "initd 0");
+	for (i = 0; i < K; i++) fprintf(G, " %a", (double)initd[i]);
+	fprintf(G, "\ninit seeds=%ld %ld %ld\n", sd1, sd2, sd3);
+	convg = calloc(r, sizeof(double));
+	c_indv = malloc(sizeof(double) * N); c_S = malloc(sizeof(double) * K); c_qq = malloc(sizeof(double) * N * K);
+	steps = (long)((u - b) / t);
+#define SEEDS() fprintf(G, " seeds=%ld %ld %ld\n", sd1, sd2, sd3)
+#define GFLAT() do { for (i = 0; i < N; i++) for (j = 0; j < L; j++) for (k = 0; k < P4; k++) gflat[((long)i * L + j) * P4 + k] = VALID(i, j) ? GENO(i, j, k) : -1; } while (0)
+	gen_polyinfo();
+	alpha = ran1() * 10;
+	fprintf(G, "chain init alpha=%a", alpha); SEEDS();
+	initial_geno();
+	GFLAT();
+	fprintf(G, "chain genoinit hgeno=%016llx", (unsigned long long)hash_i32v(gflat, (long)N * L * P4)); SEEDS();
+	for (i = 0; i < K; i++) { S[i] = initd[i]; if (back_refl == 0) state[i] = dt_stat(S[i]); }
+	update_ZQ(1);
+	fprintf(G, "chain zqinit hz=%016llx hqq=%016llx", (unsigned long long)hash_z(&D, z), (unsigned long long)hash_f64v(qq, (long)N * K)); SEEDS();
+	for (step = 0; step < u; step++) {
+		update_P_auto();
+		GFLAT();
+		count_alleles_plain(&D, gflat, z, cflat);
+		fprintf(G, "it %ld P hcnt=%016llx hfreq=%016llx", step, (unsigned long long)hash_counts(&D, cflat), (unsigned long long)hash_freq(&D, freq)); SEEDS();
+		calc_exfreq_auto();
+		fprintf(G, "it %ld X hexfreq=%016llx\n", step, (unsigned long long)hash_tables(exfreq));
+		update_S_POP();
+		fprintf(G, "it %ld S", step);
+		for (i = 0; i < K; i++) fprintf(G, " %a", S[i]);
+		if (back_refl == 0) for (i = 0; i < K; i++) fprintf(G, " st%d", state[i]);
+		fprintf(G, " hgenofreq=%016llx", (unsigned long long)hash_tables(genofreq)); SEEDS();
+		update_ZQ(0);
+		fprintf(G, "it %ld ZQ hz=%016llx hqq=%016llx hqqnum=%016llx", step, (unsigned long long)hash_z(&D, z),
+			(unsigned long long)hash_f64v(qq, (long)N * K), (unsigned long long)hash_f64v(qqnum, (long)N * K)); SEEDS();
+		update_geno();
+		GFLAT();
+		fprintf(G, "it %ld GE hgeno=%016llx", step, (unsigned long long)hash_i32v(gflat, (long)N * L * P4)); SEEDS();
+		totallkh = cal_lkd();
+		fprintf(G, "it %ld L totallkh=%a hindv=%016llx\n", step, totallkh, (unsigned long long)hash_f64v(indvlkh, N));
+		if (step == b - 1) {
+			c_step = 0; c_tot = 1; c_tot2 = 1;
+			for (i = 0; i < N; i++) c_indv[i] = 1;
+			for (i = 0; i < K; i++) c_S[i] = 1;
+			for (i = 0; i < N * K; i++) c_qq[i] = 1;
+		}
+		if (step >= b && (step + 1 - b) % t == 0) {
+#define RM(m, x) do { double *m_ = &(m), x_ = (x); if (*m_ != 0) *m_ = *m_ * ((c_step + x_ / *m_) / (1 + c_step)); else *m_ = x_ / (1 + c_step); } while (0)
+			RM(c_tot, totallkh); RM(c_tot2, totallkh * totallkh);
+			for (i = 0; i < N; i++) RM(c_indv[i], indvlkh[i]);
+			for (i = 0; i < N * K; i++) RM(c_qq[i], qq[i]);
+			for (i = 0; i < K; i++) RM(c_S[i], S[i]);
+			c_step++;
+			if (cnt_step < r) convg[cnt_step] = totallkh;
+			cnt_step++;
+		}
+		if (cnt_step == jj) {
+			for (k = 0; k < K && !flag_empty; k++) {
+				double sum = 0;
+				for (i = 0; i < N; i++) sum += qq[(long)i * K + k];
+				if (sum < 0.01) flag_empty = 1;
+			}
+			if (flag_empty) { fprintf(G, "empty_cluster at step %ld\n", step); break; }
+		}
+	}
+	fprintf(G, "chain done"); SEEDS();
+	fprintf(G, "chain steps=%ld step=%ld flag_empty=%d totallkh=%a totallkh2=%a\n", steps, c_step, flag_empty, c_tot, c_tot2);
+	dump_vec(G, "chain indvlkh", c_indv, N);
+	dump_vec(G, "chain self_rates", c_S, K);
+	for (i = 0; i < N; i++) {
+		fprintf(G, "chain qq %d", i);
+		for (k = 0; k < K; k++) fprintf(G, " %a", c_qq[i * K + k]);
+		fprintf(G, "\n");
+	}
+	dump_vec(G, "convg", convg, r);
+	fclose(G);
+	return err_flag;
+}
