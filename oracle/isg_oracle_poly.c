@@ -17,9 +17,37 @@
 #include <string.h>
 #include <ctype.h>
 #include "dump_fmt.h"
+#include "isg_math.h"
+/* genotype-class tables: the shared template (instruct_amd/csrc/isg_poly_tables.h) instantiated twice --
+ * with glibc (the reference configuration pinned to the golden files) and with the canonical math */
+#define PT_NAME(x) ptl_##x
+#define PT_LOG(x) log(x)
+#define PT_EXP(x) exp(x)
+#include "isg_poly_tables.h"
+#undef PT_NAME
+#undef PT_LOG
+#undef PT_EXP
+#define PT_NAME(x) pti_##x
+#define PT_LOG(x) isg_log(x)
+#define PT_EXP(x) isg_exp(x)
+#include "isg_poly_tables.h"
+#undef PT_NAME
+#undef PT_LOG
+#undef PT_EXP
 
 #define MIN2(X, Y) (((X) > (Y)) ? (Y) : (X))
 #define P4 4
+
+/* configuration switches (see isg_oracle.h): 0/0 = reference configuration */
+static int g_math, g_accum;
+static double m_log(double x) { return g_math ? isg_log(x) : log(x); }
+static double m_exp(double x) { return g_math ? isg_exp(x) : exp(x); }
+static double m_pow(double x, double y) { return g_math ? isg_pow(x, y) : pow(x, y); }
+static double m_sqrt(double x) { return g_math ? isg_sqrt(x) : sqrt(x); }
+typedef struct { double s; isg_acc a; } summer;
+static void sum_init(summer *s) { s->s = 0; isg_acc_zero(&s->a); }
+static void sum_add(summer *s, double v) { if (g_accum) isg_acc_add(&s->a, v); else s->s += v; }
+static double sum_val(const summer *s) { return g_accum ? isg_acc_value(&s->a) : s->s; }
 
 /* ------------------------------------------------------------------ RNG + samplers (random.c) */
 static long sd1 = 13, sd2 = 4, sd3 = 1972;
@@ -28,25 +56,30 @@ static double ran1(void)
 	sd1 = (171 * sd1) % 30269;
 	sd2 = (172 * sd2) % 30307;
 	sd3 = (170 * sd3) % 30323;
-	return fmod(sd1 / 30269.0 + sd2 / 30307.0 + sd3 / 30323.0, 1.0);
+	{
+		double x = sd1 / 30269.0 + sd2 / 30307.0 + sd3 / 30323.0;
+		if (!g_math) return fmod(x, 1.0);
+		if (x >= 2.0) x -= 2.0; else if (x >= 1.0) x -= 1.0;
+		return x;
+	}
 }
 #define E_CONST 2.71828182
 static double rgamma1(double alpha)
 {
 	double u0 = ran1(), u1 = ran1(), r, x;
 	if (u0 > E_CONST / (alpha + E_CONST)) {
-		r = -log((alpha + E_CONST) * (1 - u0) / (alpha * E_CONST));
-		if (u1 > pow(r, alpha - 1)) return -1;
+		r = -m_log((alpha + E_CONST) * (1 - u0) / (alpha * E_CONST));
+		if (u1 > m_pow(r, alpha - 1)) return -1;
 		return r;
 	}
 	x = (alpha + E_CONST) * u0 / E_CONST;
-	r = pow(x, 1 / alpha);
-	if (u1 > exp(-r)) return -1;
+	r = m_pow(x, 1 / alpha);
+	if (u1 > m_exp(-r)) return -1;
 	return r;
 }
 static double rgamma2(double alpha)
 {
-	double u1, u2, c1 = alpha - 1, c2 = (alpha - 1 / (6 * alpha)) / c1, c3 = 2 / c1, c4 = c3 + 2, c5 = 1 / sqrt(alpha), w;
+	double u1, u2, c1 = alpha - 1, c2 = (alpha - 1 / (6 * alpha)) / c1, c3 = 2 / c1, c4 = c3 + 2, c5 = 1 / m_sqrt(alpha), w;
 	do {
 		u1 = ran1();
 		u2 = ran1();
@@ -54,14 +87,14 @@ static double rgamma2(double alpha)
 	} while ((u1 >= 1) || (u1 <= 0));
 	w = c2 * u2 / u1;
 	if ((c3 * u1 + w + 1 / w) > c4)
-		if ((c3 * log(u1) - log(w) + w) >= 1) return -1;
+		if ((c3 * m_log(u1) - m_log(w) + w) >= 1) return -1;
 	return c1 * w;
 }
 static double rgamma(double alpha)
 {
 	double r = 0;
 	if (alpha < 1) do { r = rgamma1(alpha); } while (r < 0);
-	if (alpha == 1) r = -(1 / 1.0) * log(ran1());
+	if (alpha == 1) r = -(1 / 1.0) * m_log(ran1());
 	if (alpha > 1) do { r = rgamma2(alpha); } while (r < 0);
 	return r;
 }
@@ -117,9 +150,10 @@ static int chcksame(const int *p, int n) { int i, f = 0; for (i = 1; i < n; i++)
 static int nid_of(int j) { return find_id(allelenum[j], allele_poly, num_allele); }
 static int gtot(int j) { return genonum[nid_of(j)][0]; }
 
+static isg_polyclass *pclass; /* per distinct allele count */
 static void gen_polyinfo(void) /* poly_geno.c:143-184, 1673-1800 */
 {
-	int i, j, k, m, n, l, cnt, tmp, *t = malloc(sizeof(int) * (L + 1));
+	int i, j, k, cnt, tmp, *t = malloc(sizeof(int) * (L + 1));
 	cnt = 0;
 	for (i = 0; i < L; i++) if (!exists(allelenum[i], t, cnt)) t[cnt++] = allelenum[i];
 	for (i = 0; i < cnt - 1; i++) for (j = i + 1; j < cnt; j++) if (t[i] > t[j]) { tmp = t[i]; t[i] = t[j]; t[j] = tmp; }
@@ -127,44 +161,14 @@ static void gen_polyinfo(void) /* poly_geno.c:143-184, 1673-1800 */
 	allele_poly = t;
 	genonum = malloc(sizeof(*genonum) * cnt);
 	genolist = malloc(sizeof(int *) * cnt);
-	for (l = 0; l < cnt; l++) {
-		i = allele_poly[l];
-		genonum[l][1] = i;
-		genonum[l][2] = i * (i - 1);
-		genonum[l][3] = i * (i - 1) / 2;
-		genonum[l][4] = i * (i - 1) * (i - 2) / 2;
-		genonum[l][5] = i * (i - 1) * (i - 2) * (i - 3) / 24;
-		genonum[l][0] = i + i * (i - 1) * 3 / 2 + i * (i - 1) * (i - 2) / 2 + i * (i - 1) * (i - 2) * (i - 3) / 24;
-		genolist[l] = malloc(sizeof(int) * (genonum[l][0] + 1));
-		for (j = 0; j < genonum[l][1]; j++) genolist[l][j] = j * (i * i * i + i * i + i + 1);
-		tmp = genonum[l][1];
-		cnt = 0;
-		for (j = 0; j < i - 1; j++)
-			for (k = j + 1; k < i; k++) {
-				genolist[l][tmp + 2 * cnt] = j * (i * i * i + i * i + i) + k;
-				genolist[l][tmp + 2 * cnt + 1] = i * (i * i + i + 1) * k + j;
-				cnt++;
-			}
-		tmp += genonum[l][2];
-		cnt = 0;
-		for (j = 0; j < i - 1; j++)
-			for (k = j + 1; k < i; k++) genolist[l][tmp + cnt++] = j * (i * i * i + i * i) + k * (i + 1);
-		tmp += genonum[l][3];
-		cnt = 0;
-		for (j = 0; j < i - 2; j++)
-			for (k = j + 1; k < i - 1; k++)
-				for (m = k + 1; m < i; m++) {
-					genolist[l][tmp + 3 * cnt] = j * (i * i * i + i * i) + k * i + m;
-					genolist[l][tmp + 3 * cnt + 1] = k * (i * i * i + i * i) + j * i + m;
-					genolist[l][tmp + 3 * cnt + 2] = m * (i * i * i + i * i) + j * i + k;
-					cnt++;
-				}
-		tmp += genonum[l][4];
-		cnt = 0;
-		for (j = 0; j < i - 3; j++)
-			for (k = j + 1; k < i - 2; k++)
-				for (m = k + 1; m < i - 1; m++)
-					for (n = m + 1; n < i; n++) genolist[l][tmp + cnt++] = j * i * i * i + k * i * i + i * m + n;
+	pclass = malloc(sizeof(isg_polyclass) * cnt);
+	for (i = 0; i < cnt; i++) {
+		genolist[i] = malloc(sizeof(int) * (isg_poly_G(allele_poly[i]) + 1));
+		isg_poly_build(allele_poly[i], genonum[i], genolist[i]);
+		pclass[i].n = allele_poly[i];
+		pclass[i].G = genonum[i][0];
+		memcpy(pclass[i].g, genonum[i], sizeof(int) * 6);
+		pclass[i].list = genolist[i];
 	}
 	exfreq = malloc(sizeof(float *) * K * L);
 	genofreq = malloc(sizeof(float *) * K * L);
@@ -232,227 +236,22 @@ static void update_P_auto(void) /* poly_geno.c:390-438 */
 
 static void calc_exfreq_auto(void) /* poly_geno.c:1515-1590 */
 {
-	int i, j, k, m, n, digit[4], id, temp, tmp;
+	int i, k;
 	for (k = 0; k < K; k++)
 		for (i = 0; i < L; i++) {
-			float *ex = exfreq[k * L + i];
-			n = allelenum[i];
-			id = nid_of(i);
-			for (j = 0; j < genonum[id][1]; j++) {
-				tmp = genolist[id][j];
-				digit[0] = tmp % n;
-				ex[j] = (float)log(FREQ(k, i, digit[0])) * (float)P4;
-			}
-			temp = genonum[id][1];
-			for (j = temp; j < temp + genonum[id][2]; j++) {
-				tmp = genolist[id][j];
-				digit[0] = tmp % n;
-				tmp /= n;
-				digit[1] = tmp % n;
-				ex[j] = (float)(log(4.0) + log(FREQ(k, i, digit[1])) * (float)(P4 - 1) + log(FREQ(k, i, digit[0])));
-			}
-			temp += genonum[id][2];
-			for (j = temp; j < temp + genonum[id][3]; j++) {
-				tmp = genolist[id][j];
-				digit[0] = tmp % n;
-				tmp /= (n * n);
-				digit[1] = tmp % n;
-				ex[j] = (float)(log(6.0) + (log(FREQ(k, i, digit[1])) + log(FREQ(k, i, digit[0]))) * (P4 / 2));
-			}
-			temp += genonum[id][3];
-			for (j = temp; j < temp + genonum[id][4]; j++) {
-				tmp = genolist[id][j];
-				for (m = 0; m < P4 - 1; m++) { digit[m] = tmp % n; tmp /= n; }
-				ex[j] = (float)(log(12.0) + log(FREQ(k, i, digit[2])) * (P4 / 2) + log(FREQ(k, i, digit[0])) + log(FREQ(k, i, digit[1])));
-			}
-			temp += genonum[id][4];
-			for (j = temp; j < temp + genonum[id][5]; j++) {
-				tmp = genolist[id][j];
-				for (m = 0; m < P4; m++) { digit[m] = tmp % n; tmp /= n; }
-				ex[j] = (float)log(24.0);
-				for (m = 0; m < P4; m++) ex[j] += (float)log(FREQ(k, i, digit[m]));
-			}
+			if (g_math) pti_exfreq_row(&pclass[nid_of(i)], &FREQ(k, i, 0), exfreq[k * L + i]);
+			else ptl_exfreq_row(&pclass[nid_of(i)], &FREQ(k, i, 0), exfreq[k * L + i]);
 		}
 }
-
-static int calc_val(const int *num, int val, int i) /* poly_geno.c:2305-2330 */
+static void calc_self_genofreq(double self_rate, float **tab, int k, int own) /* poly_geno.c:1219-1233, 1803-2028 */
 {
-	int temp = 0;
-	if (val < num[0]) temp = val * i * i * i + num[0] * i * i + num[1] * i + num[2];
-	else if (val > num[0] && val < num[1]) temp = num[0] * i * i * i + val * i * i + num[1] * i + num[2];
-	else if (val > num[1] && val < num[2]) temp = num[0] * i * i * i + num[1] * i * i + val * i + num[2];
-	else if (val > num[2]) temp = num[0] * i * i * i + num[1] * i * i + num[2] * i + val;
-	return temp;
-}
-static int calc_val2(const int *num, int val1, int val2, int i) /* poly_geno.c:2332-2365 */
-{
-	int temp = 0;
-	if (val2 < num[1]) temp = val1 * i * i * i + val2 * i * i + num[1] * i + num[0];
-	else if (val2 > num[1] && val2 < num[0] && val1 < num[1]) temp = val1 * i * i * i + num[1] * i * i + val2 * i + num[0];
-	else if (val1 > num[1] && val2 < num[0]) temp = num[1] * i * i * i + val1 * i * i + val2 * i + num[0];
-	else if (val1 > num[1] && val1 < num[0] && val2 > num[0]) temp = num[1] * i * i * i + val1 * i * i + num[0] * i + val2;
-	else if (val1 > num[0]) temp = num[1] * i * i * i + num[0] * i * i + val1 * i + val2;
-	else if (val1 < num[1] && val2 > num[0]) temp = val1 * i * i * i + num[1] * i * i + i * num[0] + val2;
-	return temp;
-}
-
-static void gaussj3(float a[4][4], float b[4]) /* poly_geno.c:2384-2435 with n = 3, m = 1 (1-based) */
-{
-	int indxc[4], indxr[4], ipiv[4], i, icol = 1, irow = 1, j, k, l, ll, n = 3;
-	float big, dum, pivinv, temp;
-	for (j = 1; j <= n; j++) ipiv[j] = 0;
-	for (i = 1; i <= n; i++) {
-		big = 0.0;
-		for (j = 1; j <= n; j++)
-			if (ipiv[j] != 1)
-				for (k = 1; k <= n; k++)
-					if (ipiv[k] == 0)
-						if (fabs(a[j][k]) >= big) { big = fabs(a[j][k]); irow = j; icol = k; }
-		++(ipiv[icol]);
-		if (irow != icol) {
-			for (l = 1; l <= n; l++) { temp = a[irow][l]; a[irow][l] = a[icol][l]; a[icol][l] = temp; }
-			temp = b[irow]; b[irow] = b[icol]; b[icol] = temp;
-		}
-		indxr[i] = irow;
-		indxc[i] = icol;
-		if (a[icol][icol] == 0.0) { err_flag = 2; return; }
-		pivinv = 1.0 / a[icol][icol];
-		a[icol][icol] = 1.0;
-		for (l = 1; l <= n; l++) a[icol][l] *= pivinv;
-		b[icol] *= pivinv;
-		for (ll = 1; ll <= n; ll++)
-			if (ll != icol) {
-				dum = a[ll][icol];
-				a[ll][icol] = 0.0;
-				for (l = 1; l <= n; l++) a[ll][l] -= a[icol][l] * dum;
-				b[ll] -= b[icol] * dum;
-			}
+	int i, e = 0;
+	for (i = 0; i < L; i++) {
+		float *out = own ? tab[k * L + i] : tab[i];
+		if (g_math) pti_genfreq_row((float)self_rate, &pclass[nid_of(i)], exfreq[k * L + i], out, &e);
+		else ptl_genfreq_row((float)self_rate, &pclass[nid_of(i)], exfreq[k * L + i], out, &e);
 	}
-	for (l = n; l >= 1; l--)
-		if (indxr[l] != indxc[l])
-			for (k = 1; k <= n; k++) { temp = a[k][indxr[l]]; a[k][indxr[l]] = a[k][indxc[l]]; a[k][indxc[l]] = temp; }
-}
-
-/* auto_genfreq (poly_geno.c:1803-2028): log genotype frequencies under selfing rate `self` for cluster
- * pop_id at locus loci_id, solved class by class from quadri-allelic down to mono-allelic genotypes */
-static void auto_genfreq(float self, int pop_id, int loci_id, float *fr)
-{
-	int i, j, k, l, n = allelenum[loci_id], id = nid_of(loci_id), tmp, digit[3], num = 0, tri = 3;
-	const int *gl = genolist[id];
-	const int G = genonum[id][0];
-	const float *ex = exfreq[pop_id * L + loci_id];
-	float temp, matr[4][4], vec[4];
-	tmp = G;
-	if (n >= 4)
-		for (i = tmp - genonum[id][5]; i < tmp; i++) {
-			fr[i] = log(1 - self) + ex[i] - log(1 - self / 6);
-			if (fr[i] > 0) err_flag = 3;
-		}
-	if (n >= 3) {
-		tmp -= genonum[id][5];
-		for (i = 0; i < genonum[id][4] / tri; i++) {
-			num = gl[tmp - genonum[id][4] + i * 3];
-			for (j = P4 - 2; j >= 0; j--) { digit[j] = num % n; num /= n; }
-			temp = 0;
-			if (n >= 4) {
-				for (l = 0; l < n; l++)
-					if (exists(l, digit, tri) == 0) {
-						num = find_id(calc_val(digit, l, n), gl, G);
-						temp += exp(fr[num]);
-					}
-				if (temp > 1) err_flag = 3;
-			}
-			for (j = 1; j <= tri; j++) {
-				for (k = 1; k <= tri; k++) {
-					if (j == k) matr[j][k] = 1 - self * 10.0 / 36.0;
-					else matr[j][k] = -self / 9.0;
-				}
-				vec[j] = self / 18.0 * temp + (1.0 - self) * exp(ex[tmp - genonum[id][4] + i * 3 + j - 1]);
-			}
-			temp = vec[1];
-			for (j = 1; j <= tri; j++) vec[j] /= temp;
-			gaussj3(matr, vec);
-			for (j = 0; j < tri; j++) {
-				fr[tmp - genonum[id][4] + i * 3 + j] = log(vec[j + 1]) + log(temp);
-				if (fr[tmp - genonum[id][4] + i * 3 + j] > 0) err_flag = 3;
-			}
-		}
-	}
-	tmp -= genonum[id][4];
-	for (i = tmp - genonum[id][3]; i < tmp; i++) { /* duplex iijj */
-		num = gl[i];
-		digit[0] = num % n;
-		num /= (n * n);
-		digit[1] = num % n;
-		temp = 0;
-		if (n >= 3)
-			for (j = 0; j < n; j++)
-				if (exists(j, digit, 2) == 0) {
-					if (digit[0] < j) num = find_id(digit[1] * n * n * (n + 1) + digit[0] * n + j, gl, G);
-					else if (digit[0] > j) num = find_id(digit[1] * n * n * (n + 1) + j * n + digit[0], gl, G);
-					temp += exp(fr[num]) / 9.0 * self;
-					if (digit[1] < j) num = find_id(digit[0] * n * n * (n + 1) + digit[1] * n + j, gl, G);
-					else if (digit[1] > j) num = find_id(digit[0] * n * n * (n + 1) + j * n + digit[1], gl, G);
-					temp += exp(fr[num]) / 9.0 * self;
-					num = find_id(j * n * n * (n + 1) + digit[1] * n + digit[0], gl, G);
-					temp += exp(fr[num]) / 36.0 * self;
-					if (n >= 4)
-						for (k = j + 1; k < n; k++)
-							if (exists(k, digit, 2) == 0) {
-								num = find_id(calc_val2(digit, j, k, n), gl, G);
-								temp += exp(fr[num]) / 36.0 * self;
-							}
-				}
-		fr[i] = log((1 - self) * exp(ex[i]) + temp) - log(1 - self / 2.0);
-		if (fr[i] > 0) err_flag = 3;
-	}
-	tmp -= genonum[id][3];
-	for (i = tmp - genonum[id][2]; i < tmp; i++) { /* simplex iiij */
-		num = gl[i];
-		digit[0] = num % n;
-		num /= n;
-		digit[1] = num % n;
-		if (digit[0] < digit[1]) num = find_id((digit[0] * n * n + digit[1]) * (n + 1), gl, G);
-		else if (digit[0] > digit[1]) num = find_id((digit[1] * n * n + digit[0]) * (n + 1), gl, G);
-		temp = 8.0 / 36.0 * exp(fr[num]) * self;
-		if (n >= 3)
-			for (j = 0; j < n; j++)
-				if (exists(j, digit, 2) == 0) {
-					if (digit[0] < j) num = find_id(digit[1] * n * n * (n + 1) + digit[0] * n + j, gl, G);
-					else if (digit[0] > j) num = find_id(digit[1] * n * n * (n + 1) + j * n + digit[0], gl, G);
-					temp += exp(fr[num]) / 9.0 * self;
-				}
-		fr[i] = log((1 - self) * exp(ex[i]) + temp) - log(1 - self / 2.0);
-		if (fr[i] > 0) err_flag = 3;
-	}
-	tmp -= genonum[id][2];
-	for (i = tmp - genonum[id][1]; i < tmp; i++) { /* mono iiii */
-		num = gl[i];
-		digit[0] = num % n;
-		temp = 0;
-		for (j = 0; j < n; j++)
-			if (j != digit[0]) {
-				num = find_id(digit[0] * n * (n * n + n + 1) + j, gl, G);
-				temp += exp(fr[num]) / 4.0 * self;
-				/* sic: when digit[0] > j the reference's second branch repeats the first test, so the
-				 * duplex term reuses the simplex index found above (poly_geno.c:1990-1996) */
-				if (digit[0] < j) num = find_id(digit[0] * n * n * (n + 1) + j * (n + 1), gl, G);
-				temp += exp(fr[num]) / 36.0 * self;
-				if (n >= 3)
-					for (k = j + 1; k < n; k++)
-						if (k != digit[0]) {
-							num = find_id(digit[0] * n * n * (n + 1) + j * n + k, gl, G);
-							temp += exp(fr[num]) / 36.0 * self;
-						}
-			}
-		fr[i] = log((1 - self) * exp(ex[i]) + temp) - log(1 - self);
-		if (fr[i] > 0) err_flag = 3;
-	}
-}
-static void calc_self_genofreq(double self_rate, float **tab, int k, int own) /* poly_geno.c:1219-1233 */
-{
-	int i;
-	for (i = 0; i < L; i++) auto_genfreq((float)self_rate, k, i, own ? tab[k * L + i] : tab[i]);
+	if (e) err_flag = 3;
 }
 
 static int copy_num(int val, const int *vec, int leng) { int i, n = 0; for (i = 0; i < leng; i++) if (val == vec[i]) n++; return n; }
@@ -482,19 +281,54 @@ static double calc_genofq(int j, int i, const int *zz) /* poly_geno.c:1235-1286 
 	if (!VALID(i, j)) return 0;
 	gid = get_index_auto(j, &GENO(i, j, 0), &cat);
 	if (chcksame(zz, P4) == 0) return (double)genofreq[zz[0] * L + j][gid];
-	for (m = 0; m < P4; m++) ld += log(FREQ(zz[m], j, GENO(i, j, m)));
+	if (g_accum) { /* canonical: the terms are accumulated exactly by the caller */
+		err_flag |= 8;
+		return 0;
+	}
+	for (m = 0; m < P4; m++) ld += m_log(FREQ(zz[m], j, GENO(i, j, m)));
 	switch (cat) {
-	case 1: ld += log(4); break;
-	case 2: ld += log(6); break;
-	case 3: ld += log(12); break;
-	case 4: ld += log(24); break;
+	case 1: ld += m_log(4); break;
+	case 2: ld += m_log(6); break;
+	case 3: ld += m_log(12); break;
+	case 4: ld += m_log(24); break;
 	}
 	return ld;
+}
+/* the terms of one (individual, locus) added one by one to a sum (same terms, same order as calc_genofq /
+ * cal_lkd_props; with exact accumulation the order is irrelevant).  `id`/`tab`: cluster whose table is replaced */
+static void add_terms(summer *t, int i, int j, int id, float **tab)
+{
+	int cat, m, gid = get_index_auto(j, &GENO(i, j, 0), &cat);
+	const int *zz = &Z(i, j, 0);
+	if (chcksame(zz, P4) == 0) {
+		if (tab && id == zz[0]) sum_add(t, (double)tab[j][gid]);
+		else sum_add(t, (double)genofreq[zz[0] * L + j][gid]);
+		return;
+	}
+	for (m = 0; m < P4; m++) sum_add(t, m_log(FREQ(zz[m], j, GENO(i, j, m))));
+	switch (cat) {
+	case 1: sum_add(t, m_log(4)); break;
+	case 2: sum_add(t, m_log(6)); break;
+	case 3: sum_add(t, m_log(12)); break;
+	case 4: sum_add(t, m_log(24)); break;
+	}
 }
 static double cal_lkd(void) /* poly_geno.c:715-735 */
 {
 	int i, j;
 	double ld, sum = 0;
+	if (g_accum) { /* canonical: per-individual and total sums order-independent */
+		summer tot;
+		sum_init(&tot);
+		for (i = 0; i < N; i++) {
+			summer t;
+			sum_init(&t);
+			for (j = 0; j < L; j++) if (VALID(i, j)) add_terms(&t, i, j, -1, NULL);
+			indvlkh[i] = sum_val(&t);
+			sum_add(&tot, indvlkh[i]);
+		}
+		return sum_val(&tot);
+	}
 	for (i = 0; i < N; i++) {
 		ld = 0;
 		for (j = 0; j < L; j++) if (VALID(i, j)) ld += calc_genofq(j, i, &Z(i, j, 0));
@@ -503,10 +337,22 @@ static double cal_lkd(void) /* poly_geno.c:715-735 */
 	}
 	return sum;
 }
+/* canonical mode: the total log-likelihood as ONE exact sum over all terms (what the MH ratio of
+ * update_S_POP compares; the reference's cal_lkd sums per-individual subtotals) */
+static double cal_lkd_flat(int id, float **tab)
+{
+	int i, j;
+	summer t;
+	sum_init(&t);
+	for (i = 0; i < N; i++)
+		for (j = 0; j < L; j++) if (VALID(i, j)) add_terms(&t, i, j, id, tab);
+	return sum_val(&t);
+}
 static double cal_lkd_props(int id, float **tab) /* poly_geno.c:645-711 */
 {
 	int i, j, m, cat, gid;
 	double ld = 0;
+	if (g_accum) return cal_lkd_flat(id, tab);
 	for (i = 0; i < N; i++)
 		for (j = 0; j < L; j++) {
 			if (!VALID(i, j)) continue;
@@ -570,13 +416,14 @@ static void update_S_POP(void) /* poly_geno.c:584-643 */
 			tmp = adpt_indp(tem_stat + j, state[j]);
 		}
 		calc_self_genofreq(tmp, tab, j, 0);
-		mhratio = cal_lkd_props(j, tab) - cal_lkd();
+		if (g_accum) { cal_lkd(); mhratio = cal_lkd_flat(j, tab) - cal_lkd_flat(-1, NULL); } /* both totals as flat exact sums */
+		else mhratio = cal_lkd_props(j, tab) - cal_lkd();
 		if (back_refl == 0) {
 			double h = 1.0;
 			for (i = 0; i < K; i++) h *= q_trans(state[i], tem_stat[i]) / q_trans(tem_stat[i], state[i]);
 			mhratio *= h; /* sic: the Hastings factor multiplies the LOG ratio (poly_geno.c:622-623) */
 		}
-		if (ran1() < exp(MIN2(0, mhratio))) {
+		if (ran1() < m_exp(MIN2(0, mhratio))) {
 			S[j] = tmp;
 			if (back_refl == 0) state[j] = tem_stat[j];
 			for (i = 0; i < L; i++) memcpy(genofreq[j * L + i], tab[i], sizeof(float) * gtot(i));
@@ -636,17 +483,17 @@ static int choose_auto(int i, int j, int n_type) /* choose_two_auto / choose_tri
 			for (b = 0; b < K; b++) fq[a] += qq[(long)i * K + b] * FREQ(b, j, id[a]);
 		}
 		if (n_type == 2) {
-			tmp[0] = log(4) + 3 * log(fq[0]) + log(fq[1]);
-			tmp[1] = log(4) + 3 * log(fq[1]) + log(fq[0]);
-			tmp[2] = log(6) + 2 * log(fq[0]) + 2 * log(fq[1]);
+			tmp[0] = m_log(4) + 3 * m_log(fq[0]) + m_log(fq[1]);
+			tmp[1] = m_log(4) + 3 * m_log(fq[1]) + m_log(fq[0]);
+			tmp[2] = m_log(6) + 2 * m_log(fq[0]) + 2 * m_log(fq[1]);
 		} else {
-			tmp[0] = 2 * log(fq[0]) + log(fq[1]) + log(fq[2]);
-			tmp[1] = 2 * log(fq[1]) + log(fq[0]) + log(fq[2]);
-			tmp[2] = 2 * log(fq[2]) + log(fq[1]) + log(fq[0]);
+			tmp[0] = 2 * m_log(fq[0]) + m_log(fq[1]) + m_log(fq[2]);
+			tmp[1] = 2 * m_log(fq[1]) + m_log(fq[0]) + m_log(fq[2]);
+			tmp[2] = 2 * m_log(fq[2]) + m_log(fq[1]) + m_log(fq[0]);
 		}
 	}
 	tm = tmp[0];
-	for (a = 0; a < 3; a++) tmp[a] = exp(tmp[a] - tm);
+	for (a = 0; a < 3; a++) tmp[a] = m_exp(tmp[a] - tm);
 	for (a = 1; a < 3; a++) tmp[a] += tmp[a - 1];
 	return disc_unif(tmp, 3) + 1;
 }
@@ -751,7 +598,8 @@ int main(int argc, char **argv)
 	double c_tot = 1, c_tot2 = 1, *c_indv, *c_S, *c_qq;
 	long c_step = 0, steps;
 	int flag_empty = 0;
-	if (argc != 15) { fprintf(stderr, "usage: orc_dump_poly data out K N L u b t e r j s1 s2 s3\n"); return 2; }
+	if (argc != 15 && argc != 17) { fprintf(stderr, "usage: orc_dump_poly data out K N L u b t e r j s1 s2 s3 [math accum]\n"); return 2; }
+	if (argc == 17) { g_math = atoi(argv[15]); g_accum = atoi(argv[16]); }
 	K = atoi(argv[3]); u = atol(argv[6]); b = atol(argv[7]); t = atoi(argv[8]); e = atoi(argv[9]); r = atoi(argv[10]); jj = atoi(argv[11]);
 	s1 = atoi(argv[12]); s2 = atoi(argv[13]); s3 = atoi(argv[14]);
 	back_refl = e;
