@@ -116,6 +116,27 @@ int isg_set_alpha(isg_ctx *ctx, double alpha);
  */
 int isg_keyed_layout(isg_ctx *ctx, uint64_t out[9]);
 
+/*
+ * Ploidy 4 (autotetraploid, `-p 4 -ap 1`): the chain of poly_geno.c:85-116 (mcmc_POP_tetra_selfing).
+ * seqdata int32 [N][L][4]: the sorted distinct allele codes observed for (individual, locus) in the first
+ * alleleid[i][j] entries (SEQDATA.seqdata / SEQDATA.alleleid as transform_data2 leaves them,
+ * data_interface.c:571-669; alleleid 0 = missing).  cfg.P = 4, cfg.rng_sched = ISG_SCHED_REPLAY.
+ * The generic entry points then run the ploidy-4 sweeps:
+ *   isg_chain_init      initial_chn alpha + initial_geno + update_ZQ(1)   poly_geno.c:85-96, 316-369
+ *   isg_update_P        update_P_auto + calc_exfreq_auto                  poly_geno.c:390-438, 1515-1590
+ *   isg_update_S_POP    update_S_POP (tables auto_genfreq :1803-2028)     poly_geno.c:584-643
+ *   isg_update_ZQ       update_ZQ                                         poly_geno.c:750-836
+ *   isg_poly_update_geno update_geno (choose_two/tri_auto :854-960)       poly_geno.c:520-580
+ *   isg_cal_lkh         cal_lkd                                           poly_geno.c:715-735
+ *   isg_iteration       P, S_POP, ZQ, geno, lkd in the reference's order  poly_geno.c:98-116
+ * isg_update_G / isg_update_alpha fail: the reference has no such sweep on this path.
+ */
+int isg_ctx_create_poly(const isg_config *cfg, const int32_t *allelenum, const int32_t *seqdata, const int32_t *alleleid, isg_ctx **out);
+int isg_poly_update_geno(isg_ctx *ctx);
+int isg_get_poly_geno(isg_ctx *ctx, int32_t *geno);               /* [N][L][4] imputed genotypes (UPMCMC.geno), -1 unused */
+int isg_get_poly_gs(isg_ctx *ctx, int32_t *gs, int32_t *gcount);  /* table row stride; genotypes per locus [L] (may be NULL) */
+int isg_get_poly_table(isg_ctx *ctx, int which, float *out);      /* 0 exfreq, 1 genofreq: float [K][L][gs] */
+
 /* per-kernel device timing with HIP events on the launch stream (bench.py roofline) */
 int isg_profile_enable(isg_ctx *ctx, int on);
 int isg_profile_count(isg_ctx *ctx);

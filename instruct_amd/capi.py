@@ -23,7 +23,8 @@ EXPORTS = [
     "isg_get_qqnum", "isg_get_generation", "isg_get_self_rates", "isg_get_state", "isg_get_indvlkh",
     "isg_get_alpha", "isg_get_totallkh", "isg_get_amax", "isg_set_z", "isg_set_freq", "isg_set_qq",
     "isg_set_generation", "isg_set_self_rates", "isg_set_alpha", "isg_keyed_layout", "isg_profile_enable",
-    "isg_profile_count", "isg_profile_get", "isg_profile_reset", "isg_gelman_rubin",
+    "isg_profile_count", "isg_profile_get", "isg_profile_reset", "isg_gelman_rubin", "isg_selftest",
+    "isg_ctx_create_poly", "isg_poly_update_geno", "isg_get_poly_geno", "isg_get_poly_gs", "isg_get_poly_table",
 ]
 
 
@@ -218,6 +219,58 @@ class HipChain:
             self._chk(self.lib.isg_profile_get(self.h, i, name, 64, C.byref(ms), C.byref(n)))
             res[name.value.decode()] = (ms.value, n.value)
         return res
+
+
+class HipPolyChain(HipChain):
+    """One ploidy-4 (autotetraploid, ``-p 4 -ap 1``) chain on one MI355X: the sweeps of poly_geno.c:98-116.
+
+    obs: int32 [N][L][4] sorted distinct allele codes of each (individual, locus); alleleid int32 [N][L]: how many
+    (0 = missing) -- SEQDATA.seqdata / SEQDATA.alleleid as transform_data2 (data_interface.c:571-669) leaves them.
+    """
+
+    def __init__(self, obs, alleleid, allelenum, K, back_refl=1, device=0):
+        self.lib = load()
+        obs = np.ascontiguousarray(obs, dtype=np.int32)
+        self.N, self.L, self.P = obs.shape
+        self.K = K
+        allelenum = np.ascontiguousarray(allelenum, dtype=np.int32)
+        alleleid = np.ascontiguousarray(alleleid, dtype=np.int32)
+        cfg = IsgConfig(self.N, self.L, self.P, K, 2, 1, back_refl, SCHED_REPLAY, device)
+        h = C.c_void_p()
+        self._chk(self.lib.isg_ctx_create_poly(C.byref(cfg), _ptr(allelenum), _ptr(obs), _ptr(alleleid), C.byref(h)))
+        self.h = h
+        a = C.c_int32()
+        self.lib.isg_get_amax(self.h, C.byref(a))
+        self.Amax = a.value
+        self.mode = 2
+        gs = C.c_int32()
+        self.gcount = np.empty(self.L, dtype=np.int32)
+        self._chk(self.lib.isg_get_poly_gs(self.h, C.byref(gs), _ptr(self.gcount)))
+        self.GS = gs.value
+
+    def update_geno(self):
+        self._chk(self.lib.isg_poly_update_geno(self.h))
+
+    def geno(self):
+        return self._get("isg_get_poly_geno", (self.N, self.L, 4), np.int32)
+
+    def _table(self, which):
+        out = np.empty((self.K, self.L, self.GS), dtype=np.float32)
+        self._chk(self.lib.isg_get_poly_table(self.h, which, _ptr(out)))
+        return out
+
+    def exfreq(self):
+        """log expected genotype frequencies without selfing, float [K][L][GS] (calc_exfreq_auto, poly_geno.c:1515)"""
+        return self._table(0)
+
+    def genofreq(self):
+        """log genotype frequencies at the clusters' selfing rates (auto_genfreq, poly_geno.c:1803)"""
+        return self._table(1)
+
+    def packed(self, tab):
+        """the used entries of a table in the reference's order (k, j, g < G_j)"""
+        mask = np.arange(self.GS)[None, :] < self.gcount[:, None]
+        return np.ascontiguousarray(tab[:, mask])
 
 
 def gelman_rubin(vec, numchains, totrep):

@@ -88,8 +88,10 @@ struct ProfPending {
 	hipEvent_t e0, e1;
 };
 
+struct PolyCtx;
 struct isg_ctx {
 	isg_config cfg;
+	PolyCtx *poly = nullptr; /* ploidy 4 state (isg_poly_hip.inc) */
 	DevView d;
 	int Amax;
 	hipStream_t stream;
@@ -1502,10 +1504,21 @@ static void host_advance(isg_ctx *c, uint64_t n) { c->rng = isg_wh_jump(&c->tab_
 
 extern "C" const char *isg_last_error(void) { return g_err.c_str(); }
 
+/* ploidy 4 (isg_poly_hip.inc, included further down) */
+static int poly_ctx_create(const isg_config *cfg, const int32_t *allelenum, const int32_t *seq, isg_ctx **out);
+static void poly_ctx_destroy(isg_ctx *c);
+static int poly_update_P(isg_ctx *c);
+static int poly_update_S_POP(isg_ctx *c);
+static int poly_update_ZQ(isg_ctx *c, int init_flag);
+static int poly_cal_lkh(isg_ctx *c);
+static int poly_count_alleles(isg_ctx *c, int32_t *counts);
+#define NOT_POLY(c, what) if ((c)->poly) return fail(what ": not part of the ploidy 4 chain (poly_geno.c:98-116)")
+
 extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, const int32_t *geno, const int32_t *missindx, isg_ctx **out)
 {
 	*out = nullptr;
-	if (cfg->P != 2) return fail("isg_ctx_create: only diploid data (P = 2) is supported by this build");
+	if (cfg->P == 4) return fail("isg_ctx_create: ploidy 4 data goes through isg_ctx_create_poly");
+	if (cfg->P != 2) return fail("isg_ctx_create: only ploidy 2 and 4 are supported");
 	if (cfg->K < 1 || cfg->K > ISG_KCAP) return fail("isg_ctx_create: K must be in 1..32");
 	if (cfg->mode != 1 && cfg->mode != 2) return fail("isg_ctx_create: mode must be 1 or 2");
 	if (cfg->N < 1 || cfg->L < 1) return fail("isg_ctx_create: empty problem");
@@ -1636,6 +1649,14 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->cfg.device);
 	(void)hipStreamSynchronize(c->stream);
+	if (c->poly) {
+		poly_ctx_destroy(c);
+		prof_collect(c);
+		for (auto e : c->prof_free) (void)hipEventDestroy(e);
+		(void)hipStreamDestroy(c->stream);
+		delete c;
+		return;
+	}
 	DevView &d = c->d;
 	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
@@ -1775,6 +1796,7 @@ static int launch_count(isg_ctx *c)
 extern "C" int isg_count_alleles(isg_ctx *c, int32_t *counts)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
+	if (c->poly) return poly_count_alleles(c, counts);
 	if (launch_count(c)) return 1;
 	const int L = c->cfg.L, K = c->cfg.K, A = c->Amax;
 	HIPCHK(hipMemcpyAsync(c->cnt_h.data(), c->d.cnt, sizeof(int) * c->cnt_h.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1789,6 +1811,7 @@ extern "C" int isg_count_alleles(isg_ctx *c, int32_t *counts)
 extern "C" int isg_update_P(isg_ctx *c)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
+	if (c->poly) return poly_update_P(c);
 	DevView &d = c->d;
 	const int L = c->cfg.L, K = c->cfg.K, A = c->Amax;
 	if (launch_count(c)) return 1;
@@ -1826,6 +1849,7 @@ extern "C" int isg_update_S_POP(isg_ctx *c)
 {
 	if (c->cfg.mode != 2) return 0;
 	HIPCHK(hipSetDevice(c->cfg.device));
+	if (c->poly) return poly_update_S_POP(c);
 	const int K = c->cfg.K;
 	isg_wh start = is_keyed(c) ? isg_wh_jump(&c->tab_h, c->origin, iter_base(c) + c->ky[KY_OFFS]) : c->rng;
 	prof_begin(c);
@@ -1847,6 +1871,7 @@ extern "C" int isg_update_S_POP(isg_ctx *c)
 /* ---- update_G ---- */
 extern "C" int isg_update_G(isg_ctx *c)
 {
+	NOT_POLY(c, "isg_update_G");
 	if (c->cfg.mode != 2) return 0;
 	HIPCHK(hipSetDevice(c->cfg.device));
 	DevView &d = c->d;
@@ -1882,6 +1907,7 @@ static void launch_zq(isg_ctx *c, bool chain, isg_wh base, uint64_t pos0, uint64
 extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
+	if (c->poly) return poly_update_ZQ(c, init_flag);
 	const int K = c->cfg.K;
 	bool chain = !is_keyed(c);
 	isg_wh base = chain ? c->rng : c->origin;
@@ -1972,6 +1998,7 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 /* ---- update_alpha (mcmc.c:1244-1263): factors on the device, ordered product on the host ---- */
 extern "C" int isg_update_alpha(isg_ctx *c)
 {
+	NOT_POLY(c, "isg_update_alpha");
 	HIPCHK(hipSetDevice(c->cfg.device));
 	const size_t NK = (size_t)c->cfg.N * c->cfg.K;
 	if (is_keyed(c)) host_seek(c, iter_base(c) + c->ky[KY_OFFA]);
@@ -2001,6 +2028,7 @@ extern "C" int isg_update_alpha(isg_ctx *c)
 extern "C" int isg_cal_lkh(isg_ctx *c)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
+	if (c->poly) return poly_cal_lkh(c);
 	DevView &d = c->d;
 	prof_begin(c);
 	hipLaunchKernelGGL((k_loglik<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
@@ -2013,8 +2041,14 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 	return 0;
 }
 
+#include "isg_poly_hip.inc"
+
 extern "C" int isg_iteration(isg_ctx *c)
 {
+	if (c->poly) {
+		HIPCHK(hipSetDevice(c->cfg.device));
+		return poly_iteration(c);
+	}
 	if (isg_update_P(c)) return 1;
 	if (c->cfg.mode == 2) {
 		if (isg_update_S_POP(c)) return 1;
@@ -2038,6 +2072,7 @@ extern "C" int isg_run(isg_ctx *c, long n)
 extern "C" int isg_chain_init(isg_ctx *c, const float *initd)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
+	if (c->poly) return poly_chain_init(c, initd);
 	const int N = c->cfg.N, K = c->cfg.K;
 	c->origin = c->rng;
 	c->iter = 0;
@@ -2076,6 +2111,7 @@ extern "C" int isg_get_amax(isg_ctx *c, int32_t *a) { *a = c->Amax; return 0; }
 extern "C" int isg_get_z(isg_ctx *c, int32_t *z)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
+	if (c->poly) return poly_get_bytes(c, c->poly->p.z, z);
 	const int N = c->cfg.N, L = c->cfg.L, Lp = c->d.Lp;
 	std::vector<uint8_t> h((size_t)N * Lp * 2);
 	HIPCHK(hipMemcpyAsync(h.data(), c->d.z, h.size(), hipMemcpyDeviceToHost, c->stream));
@@ -2090,6 +2126,7 @@ extern "C" int isg_get_z(isg_ctx *c, int32_t *z)
 }
 extern "C" int isg_set_z(isg_ctx *c, const int32_t *z)
 {
+	NOT_POLY(c, "isg_set_z");
 	HIPCHK(hipSetDevice(c->cfg.device));
 	const int N = c->cfg.N, L = c->cfg.L, Lp = c->d.Lp;
 	std::vector<uint8_t> h((size_t)N * Lp * 2, 0xff);
@@ -2105,12 +2142,14 @@ extern "C" int isg_set_z(isg_ctx *c, const int32_t *z)
 extern "C" int isg_get_freq(isg_ctx *c, double *f)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
+	if (c->poly) { memcpy(f, c->freq.data(), sizeof(double) * c->freq.size()); return 0; } /* the host draws them */
 	if (download_freq(c)) return 1;
 	memcpy(f, c->freq.data(), sizeof(double) * c->freq.size());
 	return 0;
 }
 extern "C" int isg_set_freq(isg_ctx *c, const double *f)
 {
+	NOT_POLY(c, "isg_set_freq");
 	HIPCHK(hipSetDevice(c->cfg.device));
 	memcpy(c->freq.data(), f, sizeof(double) * c->freq.size());
 	if (upload_freq(c)) return 1;
@@ -2141,6 +2180,7 @@ extern "C" int isg_get_qqnum(isg_ctx *c, double *q)
 }
 extern "C" int isg_get_generation(isg_ctx *c, int32_t *g)
 {
+	NOT_POLY(c, "isg_get_generation");
 	HIPCHK(hipSetDevice(c->cfg.device));
 	if (ensure_gen(c)) return 1;
 	memcpy(g, c->gen.data(), sizeof(int) * c->gen.size());
@@ -2148,6 +2188,7 @@ extern "C" int isg_get_generation(isg_ctx *c, int32_t *g)
 }
 extern "C" int isg_set_generation(isg_ctx *c, const int32_t *g)
 {
+	NOT_POLY(c, "isg_set_generation");
 	HIPCHK(hipSetDevice(c->cfg.device));
 	memcpy(c->gen.data(), g, sizeof(int) * c->gen.size());
 	HIPCHK(hipMemcpy(c->d.gen, g, sizeof(int) * c->gen.size(), hipMemcpyHostToDevice));
@@ -2190,6 +2231,47 @@ extern "C" int isg_get_totallkh(isg_ctx *c, double *t)
 	HIPCHK(hipSetDevice(c->cfg.device));
 	if (ensure_lkh(c)) return 1;
 	*t = c->totallkh;
+	return 0;
+}
+
+/* ---- ploidy 4 ---- */
+extern "C" int isg_ctx_create_poly(const isg_config *cfg, const int32_t *allelenum, const int32_t *seqdata, const int32_t *alleleid, isg_ctx **out)
+{
+	*out = nullptr;
+	if (cfg->P != 4) return fail("isg_ctx_create_poly: ploidy must be 4 (autotetraploid, -ap 1)");
+	if (cfg->N < 1 || cfg->L < 1) return fail("isg_ctx_create_poly: empty problem");
+	std::vector<int32_t> seq((size_t)cfg->N * cfg->L * 4);
+	for (size_t e = 0; e < (size_t)cfg->N * cfg->L; e++)
+		for (int k = 0; k < 4; k++) seq[e * 4 + k] = k < alleleid[e] ? seqdata[e * 4 + k] : -1;
+	return poly_ctx_create(cfg, allelenum, seq.data(), out);
+}
+extern "C" int isg_poly_update_geno(isg_ctx *c)
+{
+	if (!c->poly) return fail("isg_poly_update_geno: not a ploidy 4 context");
+	HIPCHK(hipSetDevice(c->cfg.device));
+	return poly_geno_sweep(c, 0);
+}
+extern "C" int isg_get_poly_geno(isg_ctx *c, int32_t *g)
+{
+	if (!c->poly) return fail("isg_get_poly_geno: not a ploidy 4 context");
+	HIPCHK(hipSetDevice(c->cfg.device));
+	return poly_get_bytes(c, c->poly->p.geno, g);
+}
+extern "C" int isg_get_poly_gs(isg_ctx *c, int32_t *gs, int32_t *gcount /* [L] genotypes per locus */)
+{
+	if (!c->poly) return fail("isg_get_poly_gs: not a ploidy 4 context");
+	*gs = c->poly->p.GS;
+	if (gcount)
+		for (int j = 0; j < c->cfg.L; j++) gcount[j] = isg_poly_G(c->allelenum[j]);
+	return 0;
+}
+extern "C" int isg_get_poly_table(isg_ctx *c, int which, float *out)
+{
+	if (!c->poly) return fail("isg_get_poly_table: not a ploidy 4 context");
+	HIPCHK(hipSetDevice(c->cfg.device));
+	const PolyDev &p = c->poly->p;
+	HIPCHK(hipMemcpyAsync(out, which ? p.genofreq : p.exfreq, sizeof(float) * (size_t)p.K * p.L * p.GS, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
 	return 0;
 }
 

@@ -1,0 +1,108 @@
+"""GPU: ploidy 4 (autotetraploid) sweeps on the MI355X against
+ (1) the canonical configuration of the oracle (oracle/orc_dump_poly ... 1 1): every dump line identical,
+     i.e. genotypes, Z, counts, float tables, selfing rates, qq, likelihoods and seeds bit for bit;
+ (2) the golden trajectories generated from the REAL reference (tests/golden/t*.golden): discrete state
+     (imputed genotypes, Z, counts, MH states, seeds) identical, doubles within 1e-9 relative."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import orc
+
+pytestmark = pytest.mark.gpu
+DUMP = os.path.join(orc.ORC_DIR, "orc_dump_poly")
+POLY = gu.make_golden.POLY_CASES
+
+
+def hip_lines(name):
+    """Drives the C ABI sweep by sweep and formats the state as oracle/isg_oracle_poly.c's dump does."""
+    from instruct_amd import capi, synth
+    N, L, K, A, miss, u, b, t, e, r, j, seeds = POLY[name]
+    obs, alleleid, allelenum = synth.code_tetraploid(gu.make_golden.poly_data_for(name))
+    ch = capi.HipPolyChain(obs, alleleid, allelenum, K, back_refl=e)
+    ch.setseeds(*seeds)
+    initd = np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32)
+    lines = []
+    sd = lambda: " seeds=%d %d %d" % ch.seeds()
+    # the reference draws alpha, imputes the genotypes, then update_ZQ(1): chain_init does the three
+    ch.chain_init(initd)
+    lines.append("chain zqinit hz=%s hqq=%s" % (orc.fnv_i32(ch.z()), orc.fnv_f64(ch.qq())) + sd())
+    for step in range(u):
+        ch.update_P()
+        lines.append("it %d P hcnt=%s hfreq=%s" % (step, _hcnt(ch, allelenum), _hfreq(ch, allelenum)) + sd())
+        lines.append("it %d X hexfreq=%s" % (step, orc.fnv_i32(ch.packed(ch.exfreq()).view(np.int32))))
+        ch.update_S_POP()
+        s = "it %d S" % step + "".join(" " + float(x).hex() for x in ch.self_rates())
+        if e == 0:
+            s += "".join(" st%d" % x for x in ch.state())
+        lines.append(s + " hgenofreq=%s" % orc.fnv_i32(ch.packed(ch.genofreq()).view(np.int32)) + sd())
+        ch.update_ZQ(0)
+        lines.append("it %d ZQ hz=%s hqq=%s hqqnum=%s" % (step, orc.fnv_i32(ch.z()), orc.fnv_f64(ch.qq()), orc.fnv_f64(ch.qqnum())) + sd())
+        ch.update_geno()
+        lines.append("it %d GE hgeno=%s" % (step, orc.fnv_i32(ch.geno())) + sd())
+        ch.cal_lkh()
+        lines.append("it %d L totallkh=%s hindv=%s" % (step, float(ch.totallkh()).hex(), orc.fnv_f64(ch.indvlkh())))
+    ch.close()
+    return lines
+
+
+def _hcnt(ch, allelenum):
+    c = ch.count_alleles()
+    mask = np.arange(ch.Amax)[None, :] < allelenum[:, None]
+    return orc.fnv_i32(np.ascontiguousarray(c[:, mask]))
+
+
+def _hfreq(ch, allelenum):
+    f = ch.freq()
+    mask = (np.arange(ch.Amax)[None, :] < allelenum[:, None]) & (allelenum[:, None] > 1)
+    return orc.fnv_f64(np.ascontiguousarray(f[:, mask]))
+
+
+def _norm(line):
+    """C's %a and Python's float.hex differ in trailing zeros / exponent sign: compare parsed values"""
+    toks = []
+    for t in line.split():
+        k, eq, v = t.partition("=")
+        cand = v if eq else t
+        if cand.startswith(("0x", "-0x")) or cand in ("inf", "-inf", "nan"):
+            toks.append((k if eq else "") + repr(float.fromhex(cand) if "x" in cand else float(cand)))
+        else:
+            toks.append(t)
+    return " ".join(toks)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    orc.build()
+
+
+@pytest.mark.parametrize("name", sorted(POLY))
+def test_tetraploid_bit_identical_to_canonical_oracle(name, tmp_path):
+    N, L, K, A, miss, u, b, t, e, r, j, seeds = POLY[name]
+    out = str(tmp_path / (name + ".can"))
+    args = [DUMP, os.path.join(gu.GOLDEN, name + ".txt"), out] + [str(x) for x in (K, N, L, u, b, t, e, r, j) + tuple(seeds)] + ["1", "1"]
+    assert subprocess.call(args) == 0
+    want = [l for l in gu.parse(out) if l.startswith("it ") or l.startswith("chain zqinit")]
+    got = hip_lines(name)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert _norm(g) == _norm(w)
+
+
+@pytest.mark.parametrize("name", sorted(POLY))
+def test_tetraploid_matches_reference_golden(name):
+    want = [l for l in gu.parse(os.path.join(gu.GOLDEN, name + ".golden")) if l.startswith("it ") or l.startswith("chain zqinit")]
+    got = hip_lines(name)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        fg, fw = gu.fields(g), gu.fields(w)
+        for key in ("hz", "hgeno", "hcnt", "hqqnum", "seeds"):
+            assert fg.get(key) == fw.get(key), (key, g, w)
+        assert [t for t in g.split() if t.startswith("st")] == [t for t in w.split() if t.startswith("st")]
+        a, bb = gu.floats(g), gu.floats(w)
+        assert len(a) == len(bb)
+        for x, y in zip(a, bb):
+            assert x == y or (x != x and y != y) or abs(x - y) <= 1e-9 * max(abs(x), abs(y)), (g, w)
