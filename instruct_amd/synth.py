@@ -194,6 +194,50 @@ def code_tetraploid(raw: np.ndarray):
     return obs, alleleid, allelenum
 
 
+def code_tetraploid_fast(raw: np.ndarray, max_label: int = 8):
+    """Vectorised :func:`code_tetraploid` for integer labels 1..max_label (the generator's output): same
+    (obs, alleleid, allelenum), sized for the benchmark workloads (N L P ~ 1e9)."""
+    N, L, P = raw.shape
+    big = np.int64(N) * P
+    first = np.full((max_label + 1, L), big, dtype=np.int64)  # first appearance scanning individuals, then copies
+    step = max(1, (1 << 24) // max(1, L * P))
+    for i0 in range(0, N, step):
+        blk = raw[i0:i0 + step]
+        n = blk.shape[0]
+        pos = (np.arange(i0, i0 + n, dtype=np.int64)[:, None, None] * P + np.arange(P, dtype=np.int64)[None, None, :])
+        for v in range(1, max_label + 1):
+            m = np.where(blk == v, pos, big).min(axis=(0, 2))
+            np.minimum(first[v], m, out=first[v])
+    if ((raw != MISSING) & ((raw < 1) | (raw > max_label))).any():
+        raise ValueError("labels outside 1..max_label")
+    order = np.argsort(first[1:], axis=0, kind="stable")  # [label rank][L] -> label index
+    code = np.empty((max_label, L), dtype=np.int32)
+    np.put_along_axis(code, order, np.arange(max_label, dtype=np.int32)[:, None].repeat(L, 1), axis=0)
+    allelenum = (first[1:] < big).sum(axis=0).astype(np.int32)
+    obs = np.full((N, L, P), -1, dtype=np.int32)
+    alleleid = np.zeros((N, L), dtype=np.int32)
+    jj = np.arange(L)
+    for i0 in range(0, N, step):
+        blk = raw[i0:i0 + step]
+        mask = np.zeros(blk.shape[:2], dtype=np.int32)
+        for k in range(P):
+            v = blk[:, :, k]
+            ok = v != MISSING
+            c = code[np.where(ok, v, 1) - 1, jj[None, :]]
+            mask |= np.where(ok, 1 << c, 0)
+        fill = np.zeros(blk.shape[:2], dtype=np.int32)
+        o = obs[i0:i0 + step]
+        for c in range(max_label):
+            has = (mask >> c) & 1 == 1
+            slot = np.where(has, fill, P)  # P: dropped
+            for k in range(P):
+                sel = slot == k
+                o[:, :, k][sel] = c
+            fill += has
+        alleleid[i0:i0 + step] = fill
+    return obs, alleleid, allelenum
+
+
 def make_diploid(N, L, K, missing_frac=0.0, n_alleles=2, seed=20260101):
     raw = raw_alleles(N, L, K, 2, n_alleles, missing_frac, seed)
     if n_alleles == 2:

@@ -17,11 +17,26 @@ DUMP = os.path.join(orc.ORC_DIR, "orc_dump_poly")
 POLY = gu.make_golden.POLY_CASES
 
 
-def hip_lines(name):
+# generated at test time (oracle run on the GPU box's host): more alleles (up to the 6 the build supports, 126
+# genotypes per locus), more clusters, both proposal kinds
+EXTRA = {
+    "x_a4k5": (120, 200, 5, 4, 0.05, 3, 1, 1, 1, 1, 1, (21, 7, 1999)),
+    "x_a6k2": (40, 30, 2, 6, 0.05, 4, 1, 1, 0, 1, 1, (22, 8, 2000)),
+    "x_a5k12": (50, 70, 12, 5, 0.10, 3, 1, 1, 1, 1, 1, (23, 9, 2001)),
+}
+
+
+def extra_data(name):
+    from instruct_amd import synth
+    N, L, K, A, miss = EXTRA[name][:5]
+    return synth.raw_alleles(N, L, K, 4, A, miss, 20260301 + sorted(EXTRA).index(name))
+
+
+def hip_lines(name, cfg=None, raw=None):
     """Drives the C ABI sweep by sweep and formats the state as oracle/isg_oracle_poly.c's dump does."""
     from instruct_amd import capi, synth
-    N, L, K, A, miss, u, b, t, e, r, j, seeds = POLY[name]
-    obs, alleleid, allelenum = synth.code_tetraploid(gu.make_golden.poly_data_for(name))
+    N, L, K, A, miss, u, b, t, e, r, j, seeds = cfg or POLY[name]
+    obs, alleleid, allelenum = synth.code_tetraploid(raw if raw is not None else gu.make_golden.poly_data_for(name))
     ch = capi.HipPolyChain(obs, alleleid, allelenum, K, back_refl=e)
     ch.setseeds(*seeds)
     initd = np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32)
@@ -88,6 +103,22 @@ def test_tetraploid_bit_identical_to_canonical_oracle(name, tmp_path):
     want = [l for l in gu.parse(out) if l.startswith("it ") or l.startswith("chain zqinit")]
     got = hip_lines(name)
     assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert _norm(g) == _norm(w)
+
+
+@pytest.mark.parametrize("name", sorted(EXTRA))
+def test_tetraploid_generated_cases_bit_identical_to_canonical_oracle(name, tmp_path):
+    from instruct_amd import synth
+    N, L, K, A, miss, u, b, t, e, r, j, seeds = EXTRA[name]
+    raw = extra_data(name)
+    txt, out = str(tmp_path / (name + ".txt")), str(tmp_path / (name + ".can"))
+    synth.write_text_polyploid(txt, raw)
+    args = [DUMP, txt, out] + [str(x) for x in (K, N, L, u, b, t, e, r, j) + tuple(seeds)] + ["1", "1"]
+    assert subprocess.call(args) == 0
+    want = [l for l in gu.parse(out) if l.startswith("it ") or l.startswith("chain zqinit")]
+    got = hip_lines(name, EXTRA[name], raw)
+    assert len(got) == len(want) and len(got) == 1 + 6 * u
     for g, w in zip(got, want):
         assert _norm(g) == _norm(w)
 
