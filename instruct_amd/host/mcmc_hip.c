@@ -359,12 +359,22 @@ static isg_ctx *get_ctx(SEQDATA d)
 	geno = (int32_t *)malloc(sizeof(int32_t) * N * L * d.ploid);
 	miss = (int32_t *)malloc(sizeof(int32_t) * N * L);
 	if (!geno || !miss) nrerror("allocation failure while packing genotypes");
-	for (i = 0; i < N; i++)
-		for (j = 0; j < L; j++) {
-			miss[i * L + j] = d.missindx[i][j];
-			for (k = 0; k < d.ploid; k++) geno[(i * L + j) * d.ploid + k] = d.seqdata[i][j][k];
-		}
-	if (isg_ctx_create(&cfg, d.allelenum, geno, miss, &g_ctx)) hip_fail("isg_ctx_create");
+	if (d.ploid == 4) { /* distinct observed alleles + their number (transform_data2, data_interface.c:617-640) */
+		for (i = 0; i < N; i++)
+			for (j = 0; j < L; j++) {
+				miss[i * L + j] = d.alleleid[i][j];
+				for (k = 0; k < 4; k++) geno[(i * L + j) * 4 + k] = k < d.alleleid[i][j] ? d.seqdata[i][j][k] : -1;
+			}
+		cfg.rng_sched = ISG_SCHED_REPLAY;
+		if (isg_ctx_create_poly(&cfg, d.allelenum, geno, miss, &g_ctx)) hip_fail("isg_ctx_create_poly");
+	} else {
+		for (i = 0; i < N; i++)
+			for (j = 0; j < L; j++) {
+				miss[i * L + j] = d.missindx[i][j];
+				for (k = 0; k < d.ploid; k++) geno[(i * L + j) * d.ploid + k] = d.seqdata[i][j][k];
+			}
+		if (isg_ctx_create(&cfg, d.allelenum, geno, miss, &g_ctx)) hip_fail("isg_ctx_create");
+	}
 	free(geno);
 	free(miss);
 	g_ctx_key = d.seqdata;
@@ -373,7 +383,8 @@ static isg_ctx *get_ctx(SEQDATA d)
 	return g_ctx;
 }
 
-/* mcmc_POP_admixture (mcmc.c:135-179) and mcmc_POP_selfing (mcmc.c:182-239) */
+/* mcmc_POP_admixture (mcmc.c:135-179), mcmc_POP_selfing (mcmc.c:182-239) and, for ploidy 4 with -ap 1,
+ * mcmc_POP_tetra_selfing (poly_geno.c:75-140; that driver has no free_space() epilogue) */
 static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 {
 	isg_ctx *ctx = get_ctx(data);
@@ -383,6 +394,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	const int N = data.totalsize, K = data.popnum, L = data.locinum, A = data.allelenum_max;
 	double *qqflat = (double *)malloc(sizeof(double) * (size_t)N * K);
 	double *freqflat = data.print_freq == 1 ? (double *)malloc(sizeof(double) * (size_t)K * L * A) : NULL;
+	const int tetra = (data.ploid == 4);
 	int i, j, k;
 
 	memset(&mchain, 0, sizeof(mchain));
@@ -396,7 +408,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 
 	node.qq = dmatrix(0, N - 1, 0, K - 1);
 	node.indvlkh = dvector(0, N - 1);
-	if (data.mode == 2) {
+	if (data.mode == 2 || tetra) {
 		node.self_rates = dvector(0, K - 1);
 		node.generation = ivector(0, N - 1);
 		node.state = ivector(0, K - 1);
@@ -417,7 +429,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 			isg_get_qq(ctx, qqflat);
 			for (i = 0; i < N; i++)
 				for (k = 0; k < K; k++) node.qq[i][k] = qqflat[(size_t)i * K + k];
-			if (data.mode == 2) {
+			if (data.mode == 2 || tetra) {
 				isg_get_self_rates(ctx, node.self_rates);
 				isg_get_state(ctx, node.state);
 			}
@@ -426,7 +438,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 		if (step == initial.burnin - 1) allocate_chn(&mchain, data);
 		if (stored) {
 			isg_get_indvlkh(ctx, node.indvlkh);
-			if (data.mode == 2) isg_get_generation(ctx, node.generation);
+			if (data.mode == 2 && !tetra) isg_get_generation(ctx, node.generation);
 			if (data.print_freq == 1) {
 				if (isg_get_freq(ctx, freqflat)) hip_fail("isg_get_freq");
 				for (k = 0; k < K; k++)
@@ -445,7 +457,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 		}
 	}
 	/* free_space (mcmc.c:490-503) */
-	if (mchain.flag_empty_cluster == 0) {
+	if (mchain.flag_empty_cluster == 0 && !tetra) {
 		if (cnt_step != mchain.steps) nrerror("The number of iterations attained is not the same as counted");
 		fprintf(stdout, "\n\nChain %d is finished running.\n", chn + 1);
 	}
@@ -454,7 +466,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 
 	free_dmatrix(node.qq, 0, N - 1, 0, K - 1);
 	free_dvector(node.indvlkh, 0, N - 1);
-	if (data.mode == 2) {
+	if (data.mode == 2 || tetra) {
 		free_dvector(node.self_rates, 0, K - 1);
 		free_ivector(node.generation, 0, N - 1);
 		free_ivector(node.state, 0, K - 1);
@@ -470,7 +482,8 @@ CHAIN mcmc_updating(SEQDATA data, INIT initial, int chn, CONVG *cvg) /* mcmc.c:6
 	CHAIN chain;
 	memset(&chain, 0, sizeof(chain));
 	if (data.ploid == 2 && (data.mode == 1 || data.mode == 2)) return mcmc_hip_chain(data, initial, chn, cvg);
-	if (data.ploid == 4 && mcmc_POP_tetra_selfing) return mcmc_POP_tetra_selfing(data, initial, chn, cvg);
-	nrerror("this build of the sampler accelerates diploid modes 1 and 2 (-v 1, -v 2); other modes need the reference mcmc.c");
+	if (data.ploid == 4 && data.autopoly == 1) return mcmc_hip_chain(data, initial, chn, cvg);
+	if (data.ploid == 4 && mcmc_POP_tetra_selfing) return mcmc_POP_tetra_selfing(data, initial, chn, cvg); /* -ap 0: reference code */
+	nrerror("this build of the sampler accelerates diploid modes 1 and 2 (-v 1, -v 2) and autotetraploids (-p 4 -ap 1); other modes need the reference mcmc.c");
 	return chain;
 }

@@ -82,7 +82,14 @@ def main():
            "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "1"]
     with open(os.devnull, "w") as devnull:
         subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
+    # same for the ploidy 4 driver (mcmc_POP_tetra_selfing)
+    cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "t1.txt"), "-o", os.path.join(HERE, "t1_cli_output.txt")] + TETRA_CLI
+    with open(os.devnull, "w") as devnull:
+        subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
 
+
+TETRA_CLI = ["-K", "3", "-L", "40", "-N", "60", "-p", "4", "-ap", "1", "-af", "1", "-u", "60", "-b", "30", "-t", "5", "-c", "2",
+             "-v", "2", "-g", "1", "-r", "4", "-j", "4", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "0"]
 
 if __name__ == "__main__":
     main()

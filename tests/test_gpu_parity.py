@@ -263,6 +263,23 @@ def test_dropin_cli_output_equals_reference_cli_output(tmp_path):
     assert body(str(out)) == body(os.path.join(gu.GOLDEN, "c1_cli_output.txt"))
 
 
+def test_dropin_cli_output_equals_reference_cli_output_ploidy4(tmp_path):
+    """Same for `-p 4 -ap 1`: mcmc_updating routes to the MI355X ploidy-4 chain instead of poly_geno.c's driver
+    (tests/golden/t1_cli_output.txt was written by the pure reference binary)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "InStruct_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
+    out = tmp_path / "out.txt"
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "t1.txt"), "-o", str(out)] + gu.make_golden.TETRA_CLI
+    log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
+
+    def body(path):
+        return [l for l in open(path, "rb").read().split(b"\n")
+                if not (l.strip().startswith((b"Data File:", b"Output File:")) or b"InStruct" in l and b"-d" in l)]
+    assert body(str(out)) == body(os.path.join(gu.GOLDEN, "t1_cli_output.txt"))
+
+
 @pytest.fixture(scope="module")
 def full_size():
     geno, an, mi = synth.make_diploid(10000, 5000, 5)
