@@ -1920,7 +1920,7 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 		 * locus, plus each individual's Dirichlet).  Its uniforms do not depend on where the
 		 * individual boundaries fall, so they are generated up front by the whole chip; the serial
 		 * chain kernel then only reads them. */
-		uint64_t need = 2 * c->nvalid_total + 96ull * (uint64_t)c->cfg.N + 4096;
+		uint64_t need = 2 * c->nvalid_total + (uint64_t)(8 * K + 32 > 96 ? 8 * K + 32 : 96) * (uint64_t)c->cfg.N + 4096;
 		if (need > c->tape_cap) {
 			if (c->d_tape) HIPCHK(hipFree(c->d_tape));
 			c->d_tape = nullptr;

@@ -23,6 +23,8 @@ EXTRA = {
     "x_a4k5": (120, 200, 5, 4, 0.05, 3, 1, 1, 1, 1, 1, (21, 7, 1999)),
     "x_a6k2": (40, 30, 2, 6, 0.05, 4, 1, 1, 0, 1, 1, (22, 8, 2000)),
     "x_a5k12": (50, 70, 12, 5, 0.10, 3, 1, 1, 1, 1, 1, (23, 9, 2001)),
+    "x_a3k20": (30, 700, 20, 3, 0.05, 2, 1, 1, 1, 1, 1, (24, 10, 2002)),  # several workgroups per individual, K > 16
+    "x_a4k3": (25, 1500, 3, 4, 0.20, 2, 1, 1, 0, 1, 1, (25, 11, 2003)),
 }
 
 
@@ -105,6 +107,13 @@ def test_tetraploid_bit_identical_to_canonical_oracle(name, tmp_path):
     assert len(got) == len(want)
     for g, w in zip(got, want):
         assert _norm(g) == _norm(w)
+
+
+def test_tetraploid_single_workgroup_zq_kernel_gives_the_same_lines(monkeypatch):
+    """INSTRUCT_ZQ_COOP=0 selects the one-workgroup update_ZQ kernel (no uniform tape, no hand-offs)"""
+    coop = hip_lines("t1")
+    monkeypatch.setenv("INSTRUCT_ZQ_COOP", "0")
+    assert hip_lines("t1") == coop
 
 
 @pytest.mark.parametrize("name", sorted(EXTRA))
