@@ -596,6 +596,9 @@ struct ZqShared {
 	unsigned char at_used[1024];/* ... and uniforms consumed, per (gamma m, even start offset) */
 	double gval[ISG_KCAP];      /* accepted gamma values, stream order */
 	unsigned long long used_total;
+	unsigned amask[2][ISG_KCAP]; /* cooperative kernel: per gamma, bit o = the attempt at even offset o is accepted ... */
+	unsigned rmask[2][ISG_KCAP]; /* ... / did NOT consume exactly two uniforms (double buffered by individual parity) */
+	int ghist[2][ISG_KCAP];      /* cooperative kernel: the other workgroups' bucket counts */
 };
 
 /*
@@ -1045,50 +1048,204 @@ __device__ __forceinline__ unsigned long long coop_wait(const unsigned long long
 	return ((unsigned long long)hi << 32) | lo;
 }
 
+/* lane `l` of the calling wave polls granule *p until it carries `tag` (bounded; see coop_wait) */
+__device__ __forceinline__ unsigned long long coop_poll(const unsigned long long *p, unsigned tag, CoopBuf *cb)
+{
+	unsigned long long v = 0;
+	for (unsigned spin = 0;; spin++) {
+		v = ld_agent(p);
+		if ((unsigned)(v >> 48) == tag) break;
+		if ((spin & 1023u) == 1023u) {
+			if (__hip_atomic_load(&cb->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+			if (spin > (1u << 24)) {
+				__hip_atomic_store(&cb->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				break;
+			}
+		}
+		__builtin_amdgcn_s_sleep(1);
+	}
+	return v;
+}
+
+/*
+ * The Dirichlet of the cooperative kernels.  Every workgroup runs it on the same counts and gets the same
+ * consumption, so nobody has to be told where the next individual starts: ONE exchange (the counts) per
+ * individual.  Attempts are evaluated as in dirichlet_block; the walk over the attempt table is scalar: per gamma
+ * a 32-bit mask of accepted attempts and one of attempts that did not consume exactly two uniforms (a retry inside
+ * the attempt, random.c:213-216), so a step is shift / find-first-set / add on SGPRs.  Shape 1 (odd consumption)
+ * or a walk that leaves the table continue with the plain sequential loop from that point.
+ * Called by all threads after the counts are complete in sh.hist[par]; returns the uniforms consumed.
+ * `writer`: this wave stores qq[i] / qqnum[i].
+ */
+template <int BLOCK, int KMAX>
+__device__ __forceinline__ unsigned dirichlet_coop(const DevView &d, ZqShared &sh, int i, const isg_wh &cur, unsigned long long dstart_off,
+						  double alpha, int par, const double *dtape, bool writer)
+{
+	const int K = d.K, t = threadIdx.x, lane = (int)lane_id();
+	const int *hist = sh.hist[par], *ghist = sh.ghist[par]; /* own + collected counts */
+	int noff = BLOCK / K;
+	if (noff > 32) noff = 32;
+	if (t < K * noff) {
+		const int m = t / noff, o = t - m * noff;
+		const double a = (double)(hist[m] + ghist[m]) + alpha;
+		isg_cursor c;
+		c.used = 0;
+		c.tape = dtape ? dtape + 2 * o : nullptr;
+		if (!dtape) c.s = isg_wh_jump(&sh.tab, cur, dstart_off + 2ull * (unsigned)o);
+		double r = -1;
+		if (a < 1) r = isg_rgamma1_try(&c, a);
+		else if (a > 1) r = isg_rgamma2_try(&c, a);
+		else c.used = 255;
+		sh.at_val[t] = r;
+		sh.at_used[t] = (unsigned char)(c.used > 255 ? 255 : c.used);
+		if (!(r < 0)) atomicOr(&sh.amask[par][m], 1u << o);
+		if (c.used != 2) atomicOr(&sh.rmask[par][m], 1u << o);
+	}
+	if (t < KMAX) { /* the other parity's buffers: last read before the previous two barriers */
+		sh.hist[par ^ 1][t] = 0;
+		sh.ghist[par ^ 1][t] = 0;
+		sh.amask[par ^ 1][t] = 0;
+		sh.rmask[par ^ 1][t] = 0;
+	}
+	lds_barrier();
+	STAMP(i, 4);
+	/* every wave walks for itself (wave-uniform state) */
+	const unsigned am = (lane < K) ? sh.amask[par][lane] : 0u, rm = (lane < K) ? sh.rmask[par][lane] : 0u;
+	unsigned o = 0, my_o = 0;
+	int m = 0;
+	{ /* the common case straight-line: per gamma the first attempt at or after o that is accepted, none irregular */
+		unsigned fo = 0, fmy = 0;
+		bool bad = false;
+#pragma unroll
+		for (int mm = 0; mm < KMAX; mm++) {
+			if (mm < K) {
+				const unsigned A = (unsigned)__builtin_amdgcn_readlane((int)am, mm), I = (unsigned)__builtin_amdgcn_readlane((int)rm, mm);
+				const unsigned rest = (fo < 32u) ? ((A | I) >> fo) : 0u;
+				const unsigned e = fo + (rest ? (unsigned)__builtin_ctz(rest) : 0u);
+				bad |= (rest == 0u) || (((I >> (e & 31u)) & 1u) != 0u) || (e >= (unsigned)noff);
+				fmy = (lane == mm) ? e : fmy;
+				fo = e + 1u;
+			}
+		}
+		if (!bad) {
+			o = fo;
+			my_o = fmy;
+			m = K;
+		}
+	}
+	while (m < K) {
+		const unsigned A = (unsigned)__builtin_amdgcn_readlane((int)am, m), I = (unsigned)__builtin_amdgcn_readlane((int)rm, m);
+		if (o >= (unsigned)noff) break;
+		const unsigned rest = (A | I) >> o; /* the attempts before the first set bit are plain rejections: 2 uniforms each */
+		if (rest == 0) break;
+		const unsigned e = o + (unsigned)__builtin_ctz(rest);
+		unsigned step = 1;
+		if ((I >> e) & 1u) { /* a retry inside the attempt (random.c:213-216) or shape 1: consumption from the table */
+			const unsigned u = sh.at_used[m * noff + (int)e];
+			if (u == 255u || (u & 1u)) break;
+			step = u >> 1;
+		}
+		o = e + step;
+		if ((A >> e) & 1u) {
+			my_o = (lane == m) ? e : my_o;
+			m++;
+		}
+	}
+	unsigned used = 2u * o;
+	const bool ok = (m == K);
+	double v = (lane < m) ? sh.at_val[lane * noff + (int)my_o] : 0.0;
+	if (!ok) { /* wave-uniform and the same in every wave: continue sequentially from (gamma m, offset 2 o) */
+		if (t < 64) {
+			if (lane < m) sh.gval[lane] = v;
+			if (t == 0) {
+				isg_cursor c;
+				c.s = isg_wh_jump(&sh.tab, cur, dstart_off + 2ull * o);
+				c.used = 0;
+				c.tape = nullptr;
+				for (int mm = m; mm < K; mm++) sh.gval[mm] = isg_rgamma(&c, (double)(hist[mm] + ghist[mm]) + alpha);
+				sh.used_total = 2ull * o + c.used;
+			}
+		}
+		lds_barrier();
+		used = (unsigned)sh.used_total;
+		if (lane < K) v = sh.gval[lane];
+		lds_barrier(); /* gval / used_total are rewritten by the next fallback only after this */
+	}
+	STAMP(i, 5);
+	if (writer) { /* qq[i] = g / sum with the sum taken in stream order (random.c:272-279) */
+		double sum = 0;
+		for (int k2 = 0; k2 < K; k2++) sum += readlane_f64(v, k2);
+		if (lane < K) {
+			d.qq[(size_t)i * K + lane] = v / sum;
+			d.qqnum[(size_t)i * K + lane] = hist[lane] + ghist[lane];
+		}
+	}
+	return used;
+}
+
 template <int KMAX>
 __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int init_flag, double alpha, CoopBuf *cb, uint64_t *pos_out)
 {
 	constexpr int BLOCK = 256;
+	constexpr bool PRE = (KMAX <= 8);
 	__shared__ ZqShared sh;
 	const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x, K = d.K;
-	const bool leader = (g == 0);
 	const int W = (K + 2) / 3;
 	{
 		const uint16_t *src = (const uint16_t *)d.tab;
 		uint16_t *dst = (uint16_t *)&sh.tab;
 		for (int k = t; k < (int)(sizeof(isg_wh_tables) / 2); k += BLOCK) dst[k] = src[k];
-		if (t < 2 * ISG_KCAP) (&sh.hist[0][0])[t] = 0;
+		if (t < 2 * ISG_KCAP) {
+			(&sh.hist[0][0])[t] = 0;
+			(&sh.amask[0][0])[t] = 0;
+			(&sh.rmask[0][0])[t] = 0;
+			(&sh.ghist[0][0])[t] = 0;
+		}
 	}
 	__syncthreads();
-	isg_wh cur = isg_wh_jump(&sh.tab, base, 0);
-	unsigned long long off = 0; /* workgroup 0: offset of the current individual */
+	const isg_wh cur = isg_wh_jump(&sh.tab, base, 0);
+	unsigned long long off = 0; /* offset of the current individual: every workgroup derives it for itself */
 	const int stride = G * BLOCK;
 	const size_t rowb = (size_t)d.Lp * 2;
+	const bool writer = (g == 0) && (t >= BLOCK - 64);
+	const bool wmode = (G * (BLOCK / 64) * W <= BLOCK); /* one polling round covers a granule per wave */
 	double icum[KMAX];
 #pragma unroll
 	for (int m = 0; m < KMAX; m++) icum[m] = (m < K) ? (double)(m + 1) / K : 0.0; /* mcmc.c:1144 */
-	if (leader && t == 0) st_agent(&cb->pos[0], ((unsigned long long)1 << 48) | 0ull); /* individual 0 starts at offset 0 */
 	double touch = 0.0, touch2 = 0.0;
 	/* position independent data of the lane's upcoming locus, loaded one step ahead */
 	unsigned pa0 = 0xff, pa1 = 0xff, prw = 0;
 	float pF0[KMAX], pF1[KMAX];
 #pragma unroll
 	for (int m = 0; m < KMAX; m++) pF0[m] = pF1[m] = 0.f;
-	{
-		const int nj = g * BLOCK + t;
-		if (nj < d.Lp) {
-			const unsigned short gg = *(const unsigned short *)(d.geno + (size_t)nj * 2);
-			pa0 = gg & 0xff;
-			pa1 = gg >> 8;
-			prw = d.rankwave[nj >> 6];
-			if (pa0 != 0xff && KMAX <= 8 && !init_flag) {
-				const float *P0 = d.freqf + ((size_t)nj * d.Amax + pa0) * d.KPF, *P1 = d.freqf + ((size_t)nj * d.Amax + pa1) * d.KPF;
+	unsigned na0 = 0xff, na1 = 0xff, nrw = 0; /* the NEXT individual's first locus (one step further ahead) */
+	auto fetch_geno = [&](int ni, int nj, unsigned &b0, unsigned &b1, unsigned &rw) {
+		b0 = b1 = 0xff;
+		rw = 0;
+		if (ni < d.N && nj < d.Lp) {
+			const unsigned short gg = *(const unsigned short *)(d.geno + (size_t)ni * rowb + (size_t)nj * 2);
+			b0 = gg & 0xff;
+			b1 = gg >> 8;
+			rw = d.rankwave[(size_t)ni * d.nwv + (nj >> 6)];
+		}
+	};
+	auto fetch_rows = [&](int nj) {
+		if (pa0 != 0xff && PRE && !init_flag) {
+			const float *P0 = d.freqf + ((size_t)nj * d.Amax + pa0) * d.KPF, *P1 = d.freqf + ((size_t)nj * d.Amax + pa1) * d.KPF;
 #pragma unroll
-				for (int m = 0; m < KMAX; m++)
-					if (m < K) { pF0[m] = P0[m]; pF1[m] = P1[m]; }
+			for (int m = 0; m < KMAX; m += 4) {
+				if (m < K) {
+					const float4 f0 = *(const float4 *)(P0 + m), f1 = *(const float4 *)(P1 + m);
+					pF0[m] = f0.x; pF1[m] = f1.x;
+					if (m + 1 < KMAX) { pF0[m + 1] = f0.y; pF1[m + 1] = f1.y; }
+					if (m + 2 < KMAX) { pF0[m + 2] = f0.z; pF1[m + 2] = f1.z; }
+					if (m + 3 < KMAX) { pF0[m + 3] = f0.w; pF1[m + 3] = f1.w; }
+				}
 			}
 		}
-	}
+	};
+	fetch_geno(0, g * BLOCK + t, pa0, pa1, prw);
+	fetch_rows(g * BLOCK + t);
 	int pnvalid = d.nvalid[0];
 	double pq[KMAX];
 #pragma unroll
@@ -1096,7 +1253,7 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 	for (int i = 0; i < d.N; i++) {
 		const unsigned tag = (unsigned)(i % 65535) + 1u;
 		const int slot = i & (ISG_COOP_RING - 1), par = i & 1;
-		if (touch2 == -1.0) cb->overflow_flag = 2;
+		if (touch2 == -1.0 || touch == -1.0) cb->overflow_flag = 2; /* consumes last individual's cache warming loads */
 		const int nvalid = pnvalid;
 		double q[KMAX];
 		float qf[KMAX];
@@ -1105,23 +1262,15 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 			q[m] = pq[m];
 			qf[m] = (float)q[m];
 		}
-		if (i + 1 < d.N) { /* next individual's row of qq (previous iteration's values) and locus count */
-			pnvalid = d.nvalid[i + 1];
-#pragma unroll
-			for (int m = 0; m < KMAX; m++) pq[m] = (m < K && !init_flag) ? d.qq[(size_t)(i + 1) * K + m] : 0.0;
-		}
 		int wcnt[KMAX];
 #pragma unroll
 		for (int m = 0; m < KMAX; m++) wcnt[m] = 0;
-		/* the individual's start offset (the position independent loads are already in flight) */
 		STAMP(i, 0);
-		const unsigned long long pw = coop_wait(&cb->pos[slot], tag, cb);
-		STAMP(i, 1);
-		const unsigned long long offi = pw & 0xffffffffffffull;
+		const unsigned long long offi = off;
 		const bool covered = offi + 2ull * (unsigned)nvalid + 1024ull <= d.tape_len;
-		/* cache warming loads are consumed one individual later, so nothing ever waits for them */
-		if (touch == -1.0) cb->overflow_flag = 2;
-		if (leader && covered && t < 128) touch = d.tape[offi + 2ull * (unsigned)nvalid + (unsigned)t]; /* the Dirichlet's stretch */
+		/* Loads return in issue order, so everything that is only needed later is issued BEHIND the loads the
+		 * critical path waits for: the uniforms first, then the warm-up of the Dirichlet's stretch and the next
+		 * individual's data. */
 		for (int j = g * BLOCK + t; j - t < d.Lp; j += stride) { /* wave-uniform trip count */
 			const unsigned a0 = pa0, a1 = pa1;
 			const bool valid = (a0 != 0xff);
@@ -1135,42 +1284,29 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 				x0 = d.tape[offi + 2ull * rank];
 				x1 = d.tape[offi + 2ull * rank + 1];
 			}
-			/* position independent data of the lane's next locus: the next pass of this individual or
-			 * the first pass of the next one (then also a touch of the tape lines it will read) */
-			{
-				const bool more = (j - t + stride < d.Lp);
-				const int ni = more ? i : i + 1, nj = more ? j + stride : g * BLOCK + t;
-				pa0 = pa1 = 0xff;
-				prw = 0;
-				if (ni < d.N && nj < d.Lp) {
-					const unsigned short gg = *(const unsigned short *)(d.geno + (size_t)ni * rowb + (size_t)nj * 2);
-					pa0 = gg & 0xff;
-					pa1 = gg >> 8;
-					prw = d.rankwave[(size_t)ni * d.nwv + (nj >> 6)];
-					if (pa0 != 0xff && KMAX <= 8 && !init_flag) {
-						const float *P0 = d.freqf + ((size_t)nj * d.Amax + pa0) * d.KPF, *P1 = d.freqf + ((size_t)nj * d.Amax + pa1) * d.KPF;
+			if (j - t == g * BLOCK) { /* first pass */
+				if (covered && t < 10) touch = d.tape[offi + 2ull * (unsigned)nvalid + 16u * (unsigned)t]; /* one lane per 128-byte line */
+				fetch_geno(i + 1, g * BLOCK + t, na0, na1, nrw);
+				if (i + 1 < d.N) {
+					pnvalid = d.nvalid[i + 1];
 #pragma unroll
-						for (int m = 0; m < KMAX; m += 4) {
-							if (m < K) {
-								const float4 f0 = *(const float4 *)(P0 + m), f1 = *(const float4 *)(P1 + m);
-								pF0[m] = f0.x; pF1[m] = f1.x;
-								if (m + 1 < KMAX) { pF0[m + 1] = f0.y; pF1[m + 1] = f1.y; }
-								if (m + 2 < KMAX) { pF0[m + 2] = f0.z; pF1[m + 2] = f1.z; }
-								if (m + 3 < KMAX) { pF0[m + 3] = f0.w; pF1[m + 3] = f1.w; }
-							}
-						}
-					}
-					if (!more && covered) touch2 = d.tape[offi + 2ull * (unsigned)nvalid + 2ull * prw + 2u * lane_id() + 16u];
+					for (int m = 0; m < KMAX; m++) pq[m] = (m < K && !init_flag) ? d.qq[(size_t)(i + 1) * K + m] : 0.0;
 				}
 			}
+			const bool more = (j - t + stride < d.Lp);
+			if (more) { /* a further pass of this individual */
+				fetch_geno(i, j + stride, pa0, pa1, prw);
+				fetch_rows(j + stride);
+			}
 			int z0 = 0xff, z1 = 0xff;
+			STAMP(i, 6);
 			if (valid && covered) {
 				if (init_flag) {
 					z0 = bucket_fast<KMAX>(x0, icum, 1.0, K);
 					z1 = bucket_fast<KMAX>(x1, icum, 1.0, K);
 				} else {
 					bool amb0 = true, amb1 = true;
-					if (KMAX <= 8) {
+					if (PRE) {
 						z0 = bucket_f32<KMAX>((float)x0, F0, qf, K, &amb0);
 						z1 = bucket_f32<KMAX>((float)x1, F1, qf, K, &amb1);
 					}
@@ -1186,21 +1322,27 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 					}
 				}
 			}
+			STAMP(i, 7);
 #pragma unroll
 			for (int m = 0; m < KMAX; m++)
 				if (m < K) wcnt[m] += __popcll(__ballot(z0 == m)) + __popcll(__ballot(z1 == m));
 			if (j < d.Lp) *(unsigned short *)(d.z + (size_t)i * rowb + (size_t)j * 2) = (unsigned short)(z0 | (z1 << 8));
 		}
-		STAMP(i, 2);
-		if (lane_id() == 0) {
+		STAMP(i, 1);
+		if (wmode) { /* few workgroups: every wave hands its counts over itself, no reduction inside the workgroup first */
+			unsigned long long v = (unsigned long long)tag << 48;
 #pragma unroll
 			for (int m = 0; m < KMAX; m++)
-				if (m < K && wcnt[m]) atomicAdd(&sh.hist[par][m], wcnt[m]);
-		}
-		lds_barrier();
-		STAMP(i, 3);
-		if (!leader) {
-			if (t < KMAX) sh.hist[par ^ 1][t] = 0; /* before the hand-off in program order */
+				if (m < K && (int)lane_id() == m / 3) v |= (unsigned long long)(wcnt[m] & 0xffff) << (16 * (m % 3));
+			if ((int)lane_id() < W) st_agent(&cb->gran[slot][(g * (BLOCK / 64) + (t >> 6)) * W + (int)lane_id()], v);
+		} else {
+			if (lane_id() == 0) {
+#pragma unroll
+				for (int m = 0; m < KMAX; m++)
+					if (m < K && wcnt[m]) atomicAdd(&sh.hist[par][m], wcnt[m]);
+			}
+			lds_barrier();
+			/* this workgroup's counts leave; everybody else's are collected */
 			if (t < W) {
 				unsigned long long v = (unsigned long long)tag << 48;
 #pragma unroll
@@ -1208,45 +1350,35 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 					if (3 * t + c3 < K) v |= (unsigned long long)(sh.hist[par][3 * t + c3] & 0xffff) << (16 * c3);
 				st_agent(&cb->gran[slot][g * W + t], v);
 			}
-		} else {
-			/* gather the other workgroups' counts */
-			for (int gi = W + t; gi - t < G * W; gi += BLOCK) { /* wave-uniform trip count */
-				if (gi < G * W) {
-					unsigned long long v = 0;
-					for (unsigned spin = 0;; spin++) {
-						v = ld_agent(&cb->gran[slot][gi]);
-						if ((unsigned)(v >> 48) == tag) break;
-						if ((spin & 1023u) == 1023u) {
-							if (__hip_atomic_load(&cb->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-							if (spin > (1u << 24)) {
-								__hip_atomic_store(&cb->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-								break;
-							}
-						}
-						__builtin_amdgcn_s_sleep(1);
-					}
-					const int w = gi % W;
+		}
+		STAMP(i, 2);
+		/* while they travel: the frequency rows of the next individual's first locus (its genotype bytes arrived
+		 * during the draws) and a touch of the tape lines it will read */
+		pa0 = na0; pa1 = na1; prw = nrw;
+		fetch_rows(g * BLOCK + t);
+		if (covered && i + 1 < d.N && lane_id() < 10) touch2 = d.tape[offi + 2ull * (unsigned)nvalid + 2ull * prw + 16u * lane_id()];
+		if (!covered && t == 0) cb->overflow_flag = 1;
+		const int ngran = wmode ? G * (BLOCK / 64) * W : G * W;
+		for (int gi = t; gi - t < ngran; gi += BLOCK) { /* wave-uniform trip count */
+			if (gi < ngran && (wmode || gi / W != g)) {
+				const unsigned long long v = coop_poll(&cb->gran[slot][gi], tag, cb);
+				const int w = gi % W;
 #pragma unroll
-					for (int c3 = 0; c3 < 3; c3++) {
-						const int m = 3 * w + c3;
-						const int c = (int)((v >> (16 * c3)) & 0xffff);
-						if (m < K && c) atomicAdd(&sh.hist[par][m], c);
-					}
+				for (int c3 = 0; c3 < 3; c3++) {
+					const int m = 3 * w + c3;
+					const int c = (int)((v >> (16 * c3)) & 0xffff);
+					if (m < K && c) atomicAdd(&sh.ghist[par][m], c);
 				}
 			}
-			lds_barrier();
-			STAMP(i, 7);
-			if (!covered && t == 0) cb->overflow_flag = 1;
-			/* generator state = jump(cur, off + 2 nvalid): only evaluated where the tape is not used */
-			const unsigned used = 2u * (unsigned)nvalid +
-				dirichlet_block<BLOCK, KMAX>(d, sh, i, cur, alpha, par, covered ? d.tape + offi + 2ull * (unsigned)nvalid : nullptr,
-							     (i + 1 < d.N) ? &cb->pos[(i + 1) & (ISG_COOP_RING - 1)] : nullptr,
-							     off + 2ull * (unsigned)nvalid, (unsigned long long)((unsigned)((i + 1) % 65535) + 1u),
-							     off + 2ull * (unsigned)nvalid);
-			off += used;
 		}
+		lds_barrier();
+		STAMP(i, 3);
+		const unsigned used = 2u * (unsigned)nvalid +
+			dirichlet_coop<BLOCK, KMAX>(d, sh, i, cur, offi + 2ull * (unsigned)nvalid, alpha, par,
+						    covered ? d.tape + offi + 2ull * (unsigned)nvalid : nullptr, writer);
+		off += used;
 	}
-	if (leader && t == 0) *pos_out = off;
+	if (g == 0 && t == 0) *pos_out = off;
 }
 
 /* the uniforms at positions [0, n) after `base`, in stream order (8 per lane: one skip-ahead, then stepping) */

@@ -19,13 +19,14 @@ buf = np.zeros((4096, 8), dtype=np.uint64)
 h.lib.isg_diag_stamps(buf.ctypes.data_as(C.c_void_p))
 s = buf[100:min(N, 4000)].astype(np.int64)
 if os.environ.get("INSTRUCT_ZQ_COOP", "1") != "0":
-    order = [0, 1, 2, 3, 7, 4, 5, 6]
-    names = ["top->pos seen", "->draws done", "->wg barrier", "->gathered", "->attempts", "->walk", "->end barrier"]
+    order = [0, 6, 7, 1, 2, 3, 4, 5]
+    names = ["top->loads issued", "->buckets done", "->counts+store", "->published", "->gathered", "->attempts", "->walk"]
     ss = s[:, order]
     d = np.diff(ss, axis=1)
 else:
     names = ["start->draws_done", "->hist_sync1", "->hist_done", "->attempts_done", "->walk_done", "->end_sync"]
     d = np.diff(s[:, :7], axis=1)
-for n, v in zip(names, d.mean(0)):
-    print(f"{n:22s} {v:9.0f} ticks")
-print("per individual (start i+1 - start i):", np.diff(s[:, 0]).mean(), "ticks; end->next start:", (s[1:, 0] - s[:-1, 6]).mean())
+for k, (n, v) in enumerate(zip(names, d.mean(0))):
+    q = np.percentile(d[:, k], [5, 25, 50, 75, 95, 99])
+    print(f"{n:22s} {v:9.0f} ticks   pct 5/25/50/75/95/99: " + " ".join("%6.0f" % x for x in q))
+print("per individual (start i+1 - start i):", np.diff(s[:, 0]).mean(), "ticks")
