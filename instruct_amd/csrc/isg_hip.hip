@@ -1048,6 +1048,41 @@ __device__ __forceinline__ unsigned long long coop_wait(const unsigned long long
 	return ((unsigned long long)hi << 32) | lo;
 }
 
+/*
+ * isg_rgamma2_try (random.c:195-231) for the cooperative kernels' critical path.  The two logarithms only feed the
+ * accept / reject decision  c3 log(u1) - log(w) + w >= 1 ; evaluated with single precision logarithms the sign of
+ * (that - 1) is certain outside a band of 2e-6 (1 + |terms|) -- v_log_f32 is good to 1 ulp, the float image of the
+ * argument to 6e-8 -- and inside the band (or for non-finite intermediates) the double precision expression
+ * decides.  Same return value, same consumption as isg_rgamma2_try in every case.
+ */
+__device__ __forceinline__ double rgamma2_try_dev(isg_cursor *c, double alpha)
+{
+	double u1, u2, c1, c2, c3, c4, c5, w;
+	c1 = alpha - 1;
+	c2 = (alpha - 1 / (6 * alpha)) / c1;
+	c3 = 2 / c1;
+	c4 = c3 + 2;
+	c5 = 1 / isg_sqrt(alpha);
+	do {
+		u1 = isg_cur_next(c);
+		u2 = isg_cur_next(c);
+		if (alpha > 2.5) u1 = u2 + c5 * (1 - 1.86 * u1);
+	} while ((u1 >= 1) || (u1 <= 0));
+	w = c2 * u2 / u1;
+	if ((c3 * u1 + w + 1 / w) > c4) {
+		const float l1 = __builtin_amdgcn_logf((float)u1) * 0.693147180559945f, lw = __builtin_amdgcn_logf((float)w) * 0.693147180559945f;
+		const double al1 = __builtin_fabs((double)l1), alw = __builtin_fabs((double)lw);
+		const double dlt = (c3 * (double)l1 - (double)lw + w) - 1;
+		const double tol = 2e-6 * (__builtin_fabs(c3) * (1.0 + al1) + 1.0 + alw) + 1e-12 * __builtin_fabs(w);
+		bool rej;
+		if (dlt > tol) rej = true;
+		else if (dlt < -tol) rej = false;
+		else rej = (c3 * isg_log(u1) - isg_log(w) + w) >= 1;
+		if (rej) return -1;
+	}
+	return c1 * w;
+}
+
 /* lane `l` of the calling wave polls granule *p until it carries `tag` (bounded; see coop_wait) */
 __device__ __forceinline__ unsigned long long coop_poll(const unsigned long long *p, unsigned tag, CoopBuf *cb)
 {
@@ -1094,7 +1129,7 @@ __device__ __forceinline__ unsigned dirichlet_coop(const DevView &d, ZqShared &s
 		if (!dtape) c.s = isg_wh_jump(&sh.tab, cur, dstart_off + 2ull * (unsigned)o);
 		double r = -1;
 		if (a < 1) r = isg_rgamma1_try(&c, a);
-		else if (a > 1) r = isg_rgamma2_try(&c, a);
+		else if (a > 1) r = rgamma2_try_dev(&c, a);
 		else c.used = 255;
 		sh.at_val[t] = r;
 		sh.at_used[t] = (unsigned char)(c.used > 255 ? 255 : c.used);
@@ -1284,6 +1319,11 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 				x0 = d.tape[offi + 2ull * rank];
 				x1 = d.tape[offi + 2ull * rank + 1];
 			}
+#ifdef ISG_EXP_XWAIT
+			STAMP(i, 2);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			STAMP(i, 3);
+#endif
 			if (j - t == g * BLOCK) { /* first pass */
 				if (covered && t < 10) touch = d.tape[offi + 2ull * (unsigned)nvalid + 16u * (unsigned)t]; /* one lane per 128-byte line */
 				fetch_geno(i + 1, g * BLOCK + t, na0, na1, nrw);
@@ -1351,7 +1391,9 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 				st_agent(&cb->gran[slot][g * W + t], v);
 			}
 		}
+#ifndef ISG_EXP_XWAIT
 		STAMP(i, 2);
+#endif
 		/* while they travel: the frequency rows of the next individual's first locus (its genotype bytes arrived
 		 * during the draws) and a touch of the tape lines it will read */
 		pa0 = na0; pa1 = na1; prw = nrw;
@@ -1372,7 +1414,9 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 			}
 		}
 		lds_barrier();
+#ifndef ISG_EXP_XWAIT
 		STAMP(i, 3);
+#endif
 		const unsigned used = 2u * (unsigned)nvalid +
 			dirichlet_coop<BLOCK, KMAX>(d, sh, i, cur, offi + 2ull * (unsigned)nvalid, alpha, par,
 						    covered ? d.tape + offi + 2ull * (unsigned)nvalid : nullptr, writer);
