@@ -124,6 +124,7 @@ struct isg_ctx {
 	uint64_t tape_cap, nvalid_total;
 	void *d_coop;
 	int coop; /* 1: several workgroups per individual in the replay-schedule ZQ kernel */
+	int spec; /* 1: ... with the next individual's Z drawn ahead for the likely start positions (INSTRUCT_ZQ_SPEC=0 disables) */
 	int *d_state;
 	double *d_ratios, *d_total;
 	std::vector<double> ratios_h;
@@ -1055,7 +1056,21 @@ __device__ __forceinline__ unsigned long long coop_wait(const unsigned long long
  * argument to 6e-8 -- and inside the band (or for non-finite intermediates) the double precision expression
  * decides.  Same return value, same consumption as isg_rgamma2_try in every case.
  */
-__device__ __forceinline__ double rgamma2_try_dev(isg_cursor *c, double alpha)
+__device__ __forceinline__ double rgamma1_try_pre(double u0, double u1, double alpha) /* isg_rgamma1_try, uniforms drawn */
+{
+	double r, x;
+	if (u0 > ISG_E / (alpha + ISG_E)) {
+		r = -isg_log((alpha + ISG_E) * (1 - u0) / (alpha * ISG_E));
+		if (u1 > isg_pow(r, alpha - 1)) return -1;
+		return r;
+	}
+	x = (alpha + ISG_E) * u0 / ISG_E;
+	r = isg_pow(x, 1 / alpha);
+	if (u1 > isg_exp(-r)) return -1;
+	return r;
+}
+/* pu0, pu1: the first two uniforms, already drawn from *c */
+__device__ __forceinline__ double rgamma2_try_dev(isg_cursor *c, double pu0, double pu1, double alpha)
 {
 	double u1, u2, c1, c2, c3, c4, c5, w;
 	c1 = alpha - 1;
@@ -1063,11 +1078,14 @@ __device__ __forceinline__ double rgamma2_try_dev(isg_cursor *c, double alpha)
 	c3 = 2 / c1;
 	c4 = c3 + 2;
 	c5 = 1 / isg_sqrt(alpha);
-	do {
+	u1 = pu0;
+	u2 = pu1;
+	if (alpha > 2.5) u1 = u2 + c5 * (1 - 1.86 * u1);
+	while ((u1 >= 1) || (u1 <= 0)) {
 		u1 = isg_cur_next(c);
 		u2 = isg_cur_next(c);
 		if (alpha > 2.5) u1 = u2 + c5 * (1 - 1.86 * u1);
-	} while ((u1 >= 1) || (u1 <= 0));
+	}
 	w = c2 * u2 / u1;
 	if ((c3 * u1 + w + 1 / w) > c4) {
 		const float l1 = __builtin_amdgcn_logf((float)u1) * 0.693147180559945f, lw = __builtin_amdgcn_logf((float)w) * 0.693147180559945f;
@@ -1112,9 +1130,10 @@ __device__ __forceinline__ unsigned long long coop_poll(const unsigned long long
  * Called by all threads after the counts are complete in sh.hist[par]; returns the uniforms consumed.
  * `writer`: this wave stores qq[i] / qqnum[i].
  */
-template <int BLOCK, int KMAX>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int BLOCK, int KMAX, class Hook = NoHook>
 __device__ __forceinline__ unsigned dirichlet_coop(const DevView &d, ZqShared &sh, int i, const isg_wh &cur, unsigned long long dstart_off,
-						  double alpha, int par, const double *dtape, bool writer)
+						  double alpha, int par, const double *dtape, bool writer, Hook hook = Hook())
 {
 	const int K = d.K, t = threadIdx.x, lane = (int)lane_id();
 	const int *hist = sh.hist[par], *ghist = sh.ghist[par]; /* own + collected counts */
@@ -1127,15 +1146,20 @@ __device__ __forceinline__ unsigned dirichlet_coop(const DevView &d, ZqShared &s
 		c.used = 0;
 		c.tape = dtape ? dtape + 2 * o : nullptr;
 		if (!dtape) c.s = isg_wh_jump(&sh.tab, cur, dstart_off + 2ull * (unsigned)o);
+		/* the attempt's first two uniforms, then whatever the caller wants in flight behind them (loads return in
+		 * issue order: nothing issued from here on delays these two) */
+		const double pu0 = isg_cur_next(&c), pu1 = isg_cur_next(&c);
+		hook();
 		double r = -1;
-		if (a < 1) r = isg_rgamma1_try(&c, a);
-		else if (a > 1) r = rgamma2_try_dev(&c, a);
+		if (a < 1) r = rgamma1_try_pre(pu0, pu1, a);
+		else if (a > 1) r = rgamma2_try_dev(&c, pu0, pu1, a);
 		else c.used = 255;
 		sh.at_val[t] = r;
 		sh.at_used[t] = (unsigned char)(c.used > 255 ? 255 : c.used);
 		if (!(r < 0)) atomicOr(&sh.amask[par][m], 1u << o);
 		if (c.used != 2) atomicOr(&sh.rmask[par][m], 1u << o);
 	}
+	else hook();
 	if (t < KMAX) { /* the other parity's buffers: last read before the previous two barriers */
 		sh.hist[par ^ 1][t] = 0;
 		sh.ghist[par ^ 1][t] = 0;
@@ -1421,6 +1445,265 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 			dirichlet_coop<BLOCK, KMAX>(d, sh, i, cur, offi + 2ull * (unsigned)nvalid, alpha, par,
 						    covered ? d.tape + offi + 2ull * (unsigned)nvalid : nullptr, writer);
 		off += used;
+	}
+	if (g == 0 && t == 0) *pos_out = off;
+}
+
+/* bucket_f32 split in two: the running sums of a copy (position independent) and the comparison of one uniform */
+template <int KMAX>
+__device__ __forceinline__ float prefix_f32(const float (&F)[KMAX], const float (&qf)[KMAX], int K, float (&cum)[KMAX])
+{
+	float run = 0.f;
+#pragma unroll
+	for (int m = 0; m < KMAX; m++) {
+		if (m < K) run = (m == 0) ? qf[m] * F[m] : run + qf[m] * F[m];
+		cum[m] = run;
+	}
+	return run;
+}
+/* same decision as bucket_f32: the guard band test |dd| <= marg for any m is  !(min |dd| > marg) */
+template <int KMAX>
+__device__ __forceinline__ int bucket_from_cum(float xf, const float (&cum)[KMAX], float run, int K, bool *amb)
+{
+	const float p = xf * run, marg = 6e-6f * run;
+	float mn = 3.0e38f;
+	int z = 0;
+#pragma unroll
+	for (int m = 0; m < KMAX - 1; m++) {
+		if (m < K - 1) {
+			const float dd = p - cum[m];
+			z += (dd > 0.f) ? 1 : 0;
+			mn = __builtin_fminf(mn, __builtin_fabsf(dd));
+		}
+	}
+	*amb = !(mn > marg) || !(run > 1e-30f && run < 1e30f) || !(xf > 4e-6f && xf < 1.0f - 4e-6f);
+	return z;
+}
+
+/*
+ * k_zq_spec: k_zq_coop with the Z draws taken off the critical path (single pass: one locus per lane, K <= 8).
+ * Individual i+1 starts used_i uniforms behind the end of individual i's draws, and used_i = 2 K + 2 c where c is
+ * the number of rejected gamma attempts of i's Dirichlet -- almost always 0..3.  While the counts of individual i
+ * travel between the workgroups, every lane draws its two Z of individual i+1 for each of these ISG_SPEC_C start
+ * positions (the running sums are shared, a candidate costs a multiply and K-1 compares per copy).  When the
+ * Dirichlet of i is done the matching candidate is picked; any other consumption takes the plain path of
+ * k_zq_coop for that individual.  Same Z, same counts, same consumption in every case.
+ */
+#define ISG_SPEC_C 6
+template <int KMAX>
+__global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double alpha, CoopBuf *cb, uint64_t *pos_out)
+{
+	constexpr int BLOCK = 256, C = ISG_SPEC_C;
+	static_assert(KMAX <= 8 && C <= 8, "pre-filter rows in registers; candidates packed 4 bits each");
+	__shared__ ZqShared sh;
+	const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x, K = d.K, lane = (int)lane_id();
+	const int W = (K + 2) / 3;
+	{
+		const uint16_t *src = (const uint16_t *)d.tab;
+		uint16_t *dst = (uint16_t *)&sh.tab;
+		for (int k = t; k < (int)(sizeof(isg_wh_tables) / 2); k += BLOCK) dst[k] = src[k];
+		if (t < 2 * ISG_KCAP) {
+			(&sh.hist[0][0])[t] = 0;
+			(&sh.amask[0][0])[t] = 0;
+			(&sh.rmask[0][0])[t] = 0;
+			(&sh.ghist[0][0])[t] = 0;
+		}
+	}
+	__syncthreads();
+	const isg_wh cur = isg_wh_jump(&sh.tab, base, 0);
+	unsigned long long off = 0;
+	const size_t rowb = (size_t)d.Lp * 2;
+	const bool writer = (g == 0) && (t >= BLOCK - 64);
+	const bool wmode = (G * (BLOCK / 64) * W <= BLOCK);
+	const int j = g * BLOCK + t; /* this lane's locus */
+	double touch = 0.0;
+	/* three individuals in flight per lane: cl = the one being finished, nl = the one whose candidates are drawn,
+	 * ml = the one whose data is being fetched */
+	/* the individual's qq row and locus count travel as ONE vector load each (lane m holds qq[m]; they are spread
+	 * with v_readlane when used): a scalar load here would sit in the same counter as the LDS traffic and stall the
+	 * next LDS wait for a cold HBM access */
+	struct Loc {
+		unsigned a0, a1, rw;
+		float F0[KMAX], F1[KMAX];
+		double qv;
+		int nvv;
+	};
+	Loc cl, nl, ml;
+	auto fetch_geno = [&](int ni, Loc &L) {
+		L.a0 = L.a1 = 0xff;
+		L.rw = 0;
+		L.nvv = 0;
+		L.qv = 0.0;
+		if (ni < d.N) {
+			L.nvv = d.nvalid[min(ni + lane, d.N - 1)];
+			if (lane < K) L.qv = d.qq[(size_t)ni * K + lane];
+			if (j < d.Lp) {
+				const unsigned short gg = *(const unsigned short *)(d.geno + (size_t)ni * rowb + (size_t)j * 2);
+				L.a0 = gg & 0xff;
+				L.a1 = gg >> 8;
+				L.rw = d.rankwave[(size_t)ni * d.nwv + (j >> 6)];
+			}
+		}
+	};
+	auto fetch_rows = [&](Loc &L) {
+#pragma unroll
+		for (int m = 0; m < KMAX; m++) L.F0[m] = L.F1[m] = 0.f;
+		if (L.a0 != 0xff) {
+			const float *P0 = d.freqf + ((size_t)j * d.Amax + L.a0) * d.KPF, *P1 = d.freqf + ((size_t)j * d.Amax + L.a1) * d.KPF;
+#pragma unroll
+			for (int m = 0; m < KMAX; m += 4) {
+				if (m < K) {
+					const float4 f0 = *(const float4 *)(P0 + m), f1 = *(const float4 *)(P1 + m);
+					L.F0[m] = f0.x; L.F1[m] = f1.x;
+					if (m + 1 < KMAX) { L.F0[m + 1] = f0.y; L.F1[m + 1] = f1.y; }
+					if (m + 2 < KMAX) { L.F0[m + 2] = f0.z; L.F1[m + 2] = f1.z; }
+					if (m + 3 < KMAX) { L.F0[m + 3] = f0.w; L.F1[m + 3] = f1.w; }
+				}
+			}
+		}
+	};
+	fetch_geno(0, cl);
+	fetch_rows(cl);
+	fetch_geno(1, nl);
+	ml = nl;
+	/* candidates of the individual about to be finished: buckets packed 4 bits each, ambiguity bits, base offset */
+	unsigned cz0 = 0, cz1 = 0, camb = 0;
+	unsigned long long cbase = 0;
+	bool cvalid = false;
+	for (int i = 0; i < d.N; i++) {
+		const unsigned tag = (unsigned)(i % 65535) + 1u;
+		const int slot = i & (ISG_COOP_RING - 1), par = i & 1;
+		if (touch == -1.0) cb->overflow_flag = 2;
+		const int nvalid = __builtin_amdgcn_readfirstlane(cl.nvv), nnvalid = __builtin_amdgcn_readfirstlane(nl.nvv);
+		const unsigned long long offi = off;
+		const bool covered = offi + 2ull * (unsigned)nvalid + 1024ull <= d.tape_len;
+		const bool valid = (cl.a0 != 0xff);
+		const unsigned rank = cl.rw + (unsigned)__popcll(__ballot(valid) & ((1ull << lane) - 1ull));
+		STAMP(i, 0);
+		/* ---- first in the queue: the uniforms of the NEXT individual's candidates and its frequency rows ---- */
+		const unsigned long long nbase = offi + 2ull * (unsigned)nvalid + 2ull * (unsigned)K; /* every gamma: >= one attempt of two uniforms */
+		const bool nvalidc = (i + 1 < d.N) && (nbase + 2ull * (C - 1) + 2ull * (unsigned)nnvalid + 1024ull <= d.tape_len);
+		const bool nvalidl = (nl.a0 != 0xff);
+		const unsigned nrank = nl.rw + (unsigned)__popcll(__ballot(nvalidl) & ((1ull << lane) - 1ull));
+		double xs[2 * C];
+#pragma unroll
+		for (int k = 0; k < 2 * C; k++) xs[k] = 0.5;
+		if (nvalidc && nvalidl) {
+			const double *tp = d.tape + nbase + 2ull * nrank;
+#pragma unroll
+			for (int k = 0; k < 2 * C; k++) xs[k] = tp[k];
+		}
+		fetch_rows(nl);
+		if (covered && lane < 10) touch = d.tape[offi + 2ull * (unsigned)nvalid + 16u * (unsigned)lane]; /* this Dirichlet's stretch */
+		/* ---- this individual's Z: a candidate drawn earlier, or the plain path ---- */
+		const unsigned long long dc = offi - cbase;
+		const bool hit = cvalid && offi >= cbase && !(dc & 1ull) && dc < 2ull * C;
+		int z0 = 0xff, z1 = 0xff;
+		bool amb0 = false, amb1 = false;
+		if (hit) {
+			const unsigned c = (unsigned)(dc >> 1);
+			if (valid) {
+				z0 = (int)((cz0 >> (4 * c)) & 0xfu);
+				z1 = (int)((cz1 >> (4 * c)) & 0xfu);
+				amb0 = (camb >> c) & 1u;
+				amb1 = (camb >> (8 + c)) & 1u;
+			}
+		} else if (valid && covered) {
+			float qf[KMAX];
+#pragma unroll
+			for (int m = 0; m < KMAX; m++) qf[m] = (m < K) ? (float)readlane_f64(cl.qv, m) : 0.f;
+			const double x0 = d.tape[offi + 2ull * rank], x1 = d.tape[offi + 2ull * rank + 1];
+			z0 = bucket_f32<KMAX>((float)x0, cl.F0, qf, K, &amb0);
+			z1 = bucket_f32<KMAX>((float)x1, cl.F1, qf, K, &amb1);
+		}
+		if (__ballot(valid && covered && (amb0 || amb1))) { /* rare: the draw in double */
+			double cum[KMAX], q[KMAX];
+#pragma unroll
+			for (int m = 0; m < KMAX; m++) q[m] = (m < K) ? readlane_f64(cl.qv, m) : 0.0;
+			if (valid && covered && amb0) {
+				const double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + cl.a0) * d.KP, q, cum, K);
+				z0 = bucket_fast<KMAX>(d.tape[offi + 2ull * rank], cum, tot, K);
+			}
+			if (valid && covered && amb1) {
+				const double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + cl.a1) * d.KP, q, cum, K);
+				z1 = bucket_fast<KMAX>(d.tape[offi + 2ull * rank + 1], cum, tot, K);
+			}
+		}
+		if (!covered) { z0 = z1 = 0xff; }
+		int wcnt[KMAX];
+#pragma unroll
+		for (int m = 0; m < KMAX; m++) wcnt[m] = (m < K) ? __popcll(__ballot(z0 == m)) + __popcll(__ballot(z1 == m)) : 0;
+		STAMP(i, 1);
+		/* ---- counts leave ---- */
+		if (wmode) {
+			unsigned long long v = (unsigned long long)tag << 48;
+#pragma unroll
+			for (int m = 0; m < KMAX; m++)
+				if (m < K && lane == m / 3) v |= (unsigned long long)(wcnt[m] & 0xffff) << (16 * (m % 3));
+			if (lane < W) st_agent(&cb->gran[slot][(g * (BLOCK / 64) + (t >> 6)) * W + lane], v);
+		} else {
+			if (lane == 0) {
+#pragma unroll
+				for (int m = 0; m < KMAX; m++)
+					if (m < K && wcnt[m]) atomicAdd(&sh.hist[par][m], wcnt[m]);
+			}
+			lds_barrier();
+			if (t < W) {
+				unsigned long long v = (unsigned long long)tag << 48;
+#pragma unroll
+				for (int c3 = 0; c3 < 3; c3++)
+					if (3 * t + c3 < K) v |= (unsigned long long)(sh.hist[par][3 * t + c3] & 0xffff) << (16 * c3);
+				st_agent(&cb->gran[slot][g * W + t], v);
+			}
+		}
+		if (j < d.Lp) *(unsigned short *)(d.z + (size_t)i * rowb + (size_t)j * 2) = (unsigned short)(z0 | (z1 << 8));
+		STAMP(i, 2);
+		if (!covered && t == 0) cb->overflow_flag = 1;
+		/* ---- while they travel: the data of the individual after the next is requested (cold: it arrives under
+		 * the arithmetic below, before the polling loads queue up behind it), then the next one's candidates ---- */
+		fetch_geno(i + 2, ml);
+		cbase = nbase;
+		cvalid = nvalidc;
+		cz0 = cz1 = camb = 0;
+		if (nvalidc && nvalidl) {
+			float qf[KMAX], cum0[KMAX], cum1[KMAX];
+#pragma unroll
+			for (int m = 0; m < KMAX; m++) qf[m] = (m < K) ? (float)readlane_f64(nl.qv, m) : 0.f;
+			const float run0 = prefix_f32<KMAX>(nl.F0, qf, K, cum0), run1 = prefix_f32<KMAX>(nl.F1, qf, K, cum1);
+#pragma unroll
+			for (int c = 0; c < C; c++) {
+				bool a0, a1;
+				const int b0 = bucket_from_cum<KMAX>((float)xs[2 * c], cum0, run0, K, &a0);
+				const int b1 = bucket_from_cum<KMAX>((float)xs[2 * c + 1], cum1, run1, K, &a1);
+				cz0 |= (unsigned)b0 << (4 * c);
+				cz1 |= (unsigned)b1 << (4 * c);
+				camb |= (a0 ? 1u : 0u) << c;
+				camb |= (a1 ? 1u : 0u) << (8 + c);
+			}
+		}
+		STAMP(i, 6);
+		/* ---- everybody's counts ---- */
+		const int ngran = wmode ? G * (BLOCK / 64) * W : G * W;
+		for (int gi = t; gi - t < ngran; gi += BLOCK) { /* wave-uniform trip count */
+			if (gi < ngran && (wmode || gi / W != g)) {
+				const unsigned long long v = coop_poll(&cb->gran[slot][gi], tag, cb);
+				const int w = gi % W;
+#pragma unroll
+				for (int c3 = 0; c3 < 3; c3++) {
+					const int m = 3 * w + c3;
+					const int c = (int)((v >> (16 * c3)) & 0xffff);
+					if (m < K && c) atomicAdd(&sh.ghist[par][m], c);
+				}
+			}
+		}
+		lds_barrier();
+		STAMP(i, 3);
+		const unsigned used = 2u * (unsigned)nvalid +
+			dirichlet_coop<BLOCK, KMAX>(d, sh, i, cur, offi + 2ull * (unsigned)nvalid, alpha, par,
+						    covered ? d.tape + offi + 2ull * (unsigned)nvalid : nullptr, writer);
+		off += used;
+		cl = nl;
+		nl = ml;
 	}
 	if (g == 0 && t == 0) *pos_out = off;
 }
@@ -1775,6 +2058,8 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 		c->d_coop = cbp;
 		const char *e = getenv("INSTRUCT_ZQ_COOP");
 		c->coop = (e && atoi(e) == 0) ? 0 : 1;
+		e = getenv("INSTRUCT_ZQ_SPEC");
+		c->spec = (e && atoi(e) == 0) ? 0 : 1;
 	}
 	DALLOC(d.cnt, int, (size_t)Lp * Amax * K);
 	DALLOC(d.qq, double, (size_t)N * K);
@@ -2118,6 +2403,18 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 		CoopBuf *cb = (CoopBuf *)c->d_coop;
 		prof_begin(c);
 #define COOP_LAUNCH(KM) hipLaunchKernelGGL((k_zq_coop<KM>), dim3(G), dim3(256), 0, c->stream, c->d, base, init_flag, c->alpha, cb, c->d_pos)
+#define SPEC_LAUNCH(KM) hipLaunchKernelGGL((k_zq_spec<KM>), dim3(G), dim3(256), 0, c->stream, c->d, base, c->alpha, cb, c->d_pos)
+		const bool spec = !init_flag && K <= 8 && G * 256 >= c->d.Lp && c->spec;
+		if (spec) {
+			switch (K) {
+			case 1: case 2: SPEC_LAUNCH(2); break;
+			case 3: SPEC_LAUNCH(3); break;
+			case 4: SPEC_LAUNCH(4); break;
+			case 5: SPEC_LAUNCH(5); break;
+			case 6: SPEC_LAUNCH(6); break;
+			default: SPEC_LAUNCH(8); break;
+			}
+		} else
 		switch (K) {
 		case 1: case 2: COOP_LAUNCH(2); break;
 		case 3: COOP_LAUNCH(3); break;
@@ -2132,7 +2429,7 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 			else COOP_LAUNCH(32);
 		}
 #undef COOP_LAUNCH
-		prof_end(c, "k_zq_coop");
+		prof_end(c, spec ? "k_zq_spec" : "k_zq_coop");
 		HIPCHK(hipGetLastError());
 		uint64_t used = 0;
 		unsigned flags[2] = {0, 0};
