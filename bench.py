@@ -118,6 +118,59 @@ def cpu_baseline(geno, K, seeds):
     return {"value": round(1.0 / dt, 6), "unit": "iterations/s", "cores": 1, "kind": "port", "sample": sample, "s_per_iter": dt}
 
 
+def tetra_leg(device, steps, warmup, with_cpu):
+    """BASELINE.json config 5 on one GPU: N=10000 L=20000 K=10 ploidy 4 (autotetraploid), 5 % missing, replay
+    schedule.  The synthetic population is 1000 distinct individuals x 10 replicas (the generator's numpy
+    coder takes minutes at 8e8 allele copies); every replica is sampled independently by the chain."""
+    N, L, K, A, base = 10000, 20000, 10, 4, 1000
+    raw = synth.raw_alleles(base, L, K, 4, A, 0.05, 20260105)
+    obs, alleleid, allelenum = synth.code_tetraploid_fast(raw)
+    obs, alleleid = np.tile(obs, (N // base, 1, 1)), np.tile(alleleid, (N // base, 1))
+    ch = capi.HipPolyChain(obs, alleleid, allelenum, K, back_refl=1, device=device)
+    ch.setseeds(13, 4, 1972)
+    ch.chain_init(np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32))
+    ch.run(warmup)
+    ch.profile_reset()
+    ch.profile(True)
+    sync()
+    t0 = time.perf_counter()
+    ch.run(steps)
+    last = ch.totallkh()
+    sync()
+    dt = time.perf_counter() - t0
+    ch.profile(False)
+    prof = ch.profile_results()
+    ch.close()
+    nvalid = int((alleleid > 0).sum())
+    zq = "k4_zq_coop" if "k4_zq_coop" in prof else "k4_zq"
+    res = {"workload": "config5: N=10000 L=20000 K=10 ploidy 4 (-p 4 -ap 1), 5% missing, 1 chain, replay schedule",
+           "value": round(steps / dt, 4), "unit": "iterations/s", "ms_per_step": round(dt / steps * 1e3, 3),
+           "roofline": roofline(prof, zq, 2 * 4 * nvalid + 8 * 4 * nvalid, None),  # genotype + Z byte per copy, one tape double per copy
+           "kernels_ms": {k: round(ms / n, 4) for k, (ms, n) in sorted(prof.items())},
+           "iteration_frac_of_hbm": round(5 * N * L * 4 / (dt / steps) / 1e9 / HBM_PEAK_GBS, 6), "last_totallkh": last}
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump_poly")
+    if with_cpu and os.path.exists(exe):
+        # the reference's own ploidy-4 chain (poly_geno.c) on one host core at 1/400 of the allele copies; the
+        # per-iteration time is the difference of a 4- and a 2-iteration run (reading and set-up cancel)
+        n, l = 250, 2000
+        with tempfile.TemporaryDirectory() as tmp:
+            txt = os.path.join(tmp, "t.txt")
+            synth.write_text_polyploid(txt, synth.raw_alleles(n, l, K, 4, A, 0.05, 20260105))
+            ts = []
+            for u in (2, 4):
+                t0 = time.perf_counter()
+                subprocess.run([exe, txt, os.path.join(tmp, "o"), str(K), str(n), str(l), str(u), "1", "1", "1", "1", "1", "13", "4", "1972"],
+                               stdout=subprocess.DEVNULL, check=True, timeout=900)
+                ts.append(time.perf_counter() - t0)
+        s_small = (ts[1] - ts[0]) / 2
+        scale = (N * L) / (n * l)
+        res["cpu_baseline"] = {"value": round(1.0 / (s_small * scale), 8), "unit": "iterations/s", "cores": 1, "kind": "reference",
+                               "sample": f"reference poly_geno.c chain at N={n} L={l} K={K} ({s_small:.3f} s/iteration), scaled by N*L = x{scale:.0f} (every sweep is linear in N*L)",
+                               "s_per_iter_extrapolated": round(s_small * scale, 1)}
+        res["speedup_vs_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +179,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-keyed", action="store_true")
+    ap.add_argument("--no-tetra", action="store_true", help="skip the ploidy 4 (config 5) leg")
     args = ap.parse_args()
 
     import torch
@@ -199,6 +253,8 @@ def main():
                              "speedup_vs_cpu": (round(k["value"] / world / cpu["value"], 2) if cpu else None),
                              "gelman_rubin": k["gelman_rubin"],
                              "note": "counter-based stream positions: bit-identical to the oracle's keyed schedule, statistically equivalent to the reference"}
+        if world == 1 and not args.no_tetra:
+            line["ploidy4"] = tetra_leg(local, max(2, args.steps // 4), 1, not args.no_cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
