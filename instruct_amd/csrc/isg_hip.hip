@@ -125,6 +125,7 @@ struct isg_ctx {
 	void *d_coop;
 	int coop; /* 1: several workgroups per individual in the replay-schedule ZQ kernel */
 	int spec; /* 1: ... with the next individual's Z drawn ahead for the likely start positions (INSTRUCT_ZQ_SPEC=0 disables) */
+	int xcd;  /* 1: try to place the cooperating workgroups on one XCD (INSTRUCT_ZQ_XCD=1 enables) */
 	int *d_state;
 	double *d_ratios, *d_total;
 	std::vector<double> ratios_h;
@@ -1018,6 +1019,7 @@ struct CoopBuf {
 	unsigned long long gran[ISG_COOP_RING][ISG_COOP_GMAX * ISG_COOP_WMAX];
 	unsigned abort_flag;
 	unsigned overflow_flag;
+	unsigned long long xcc[ISG_COOP_GMAX]; /* which XCD each workgroup runs on (tagged), for the same-XCD fast path */
 };
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p)
 {
@@ -1027,6 +1029,24 @@ __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long lo
 {
 	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+/* store that stays in the XCD's L2 (no write-through to the memory side): visible to agent-scope loads of
+ * workgroups on the SAME XCD only -- used after the workgroups have established that they share one */
+__device__ __forceinline__ void st_xcd(unsigned long long *p, unsigned long long v)
+{
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned xcc_id()
+{
+	unsigned x;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+	return x & 0xfu;
+}
+/*
+ * Do all G workgroups of this launch run on one XCD?  (Blocks are dealt round-robin over the 8 XCDs, so the
+ * launcher starts 8 G blocks of which every 8th works; this only makes it likely -- the answer comes from the
+ * hardware register.)  One tagged agent-scope word per workgroup, everybody reads all of them.
+ */
+__device__ __forceinline__ bool coop_same_xcd(CoopBuf *cb, int g, int G, unsigned *lds_flag);
 /* lane 0 of the calling wave polls *p until its top 16 bits equal tag; the word is returned to all lanes */
 __device__ __forceinline__ unsigned long long coop_wait(const unsigned long long *p, unsigned tag, CoopBuf *cb)
 {
@@ -1118,6 +1138,22 @@ __device__ __forceinline__ unsigned long long coop_poll(const unsigned long long
 		__builtin_amdgcn_s_sleep(1);
 	}
 	return v;
+}
+
+__device__ __forceinline__ bool coop_same_xcd(CoopBuf *cb, int g, int G, unsigned *lds_flag)
+{
+	const int t = threadIdx.x;
+	if (t == 0) {
+		*lds_flag = 1u;
+		st_agent(&cb->xcc[g], (1ull << 48) | xcc_id());
+	}
+	__syncthreads();
+	if (t < G) {
+		const unsigned long long v = coop_poll(&cb->xcc[t], 1u, cb);
+		if ((unsigned)(v >> 48) != 1u || (unsigned)(v & 0xfu) != xcc_id()) atomicAnd(lds_flag, 0u);
+	}
+	__syncthreads();
+	return *lds_flag != 0u;
 }
 
 /*
@@ -1243,12 +1279,14 @@ __device__ __forceinline__ unsigned dirichlet_coop(const DevView &d, ZqShared &s
 }
 
 template <int KMAX>
-__global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int init_flag, double alpha, CoopBuf *cb, uint64_t *pos_out)
+__global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int init_flag, double alpha, CoopBuf *cb, uint64_t *pos_out, int xcd_pack)
 {
 	constexpr int BLOCK = 256;
 	constexpr bool PRE = (KMAX <= 8);
 	__shared__ ZqShared sh;
-	const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x, K = d.K;
+	__shared__ unsigned same_xcd;
+	if (xcd_pack && (blockIdx.x & 7)) return; /* every 8th block works: one XCD under round-robin placement */
+	const int t = threadIdx.x, g = xcd_pack ? blockIdx.x >> 3 : blockIdx.x, G = xcd_pack ? gridDim.x >> 3 : gridDim.x, K = d.K;
 	const int W = (K + 2) / 3;
 	{
 		const uint16_t *src = (const uint16_t *)d.tab;
@@ -1262,6 +1300,7 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 		}
 	}
 	__syncthreads();
+	const bool local = xcd_pack && coop_same_xcd(cb, g, G, &same_xcd);
 	const isg_wh cur = isg_wh_jump(&sh.tab, base, 0);
 	unsigned long long off = 0; /* offset of the current individual: every workgroup derives it for itself */
 	const int stride = G * BLOCK;
@@ -1398,7 +1437,7 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 #pragma unroll
 			for (int m = 0; m < KMAX; m++)
 				if (m < K && (int)lane_id() == m / 3) v |= (unsigned long long)(wcnt[m] & 0xffff) << (16 * (m % 3));
-			if ((int)lane_id() < W) st_agent(&cb->gran[slot][(g * (BLOCK / 64) + (t >> 6)) * W + (int)lane_id()], v);
+			if ((int)lane_id() < W) { if (local) st_xcd(&cb->gran[slot][(g * (BLOCK / 64) + (t >> 6)) * W + (int)lane_id()], v); else st_agent(&cb->gran[slot][(g * (BLOCK / 64) + (t >> 6)) * W + (int)lane_id()], v); }
 		} else {
 			if (lane_id() == 0) {
 #pragma unroll
@@ -1412,7 +1451,7 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 #pragma unroll
 				for (int c3 = 0; c3 < 3; c3++)
 					if (3 * t + c3 < K) v |= (unsigned long long)(sh.hist[par][3 * t + c3] & 0xffff) << (16 * c3);
-				st_agent(&cb->gran[slot][g * W + t], v);
+				if (local) st_xcd(&cb->gran[slot][g * W + t], v); else st_agent(&cb->gran[slot][g * W + t], v);
 			}
 		}
 #ifndef ISG_EXP_XWAIT
@@ -1489,14 +1528,18 @@ __device__ __forceinline__ int bucket_from_cum(float xf, const float (&cum)[KMAX
  * Dirichlet of i is done the matching candidate is picked; any other consumption takes the plain path of
  * k_zq_coop for that individual.  Same Z, same counts, same consumption in every case.
  */
+#ifndef ISG_SPEC_C
 #define ISG_SPEC_C 6
+#endif
 template <int KMAX>
-__global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double alpha, CoopBuf *cb, uint64_t *pos_out)
+__global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double alpha, CoopBuf *cb, uint64_t *pos_out, int xcd_pack)
 {
 	constexpr int BLOCK = 256, C = ISG_SPEC_C;
 	static_assert(KMAX <= 8 && C <= 8, "pre-filter rows in registers; candidates packed 4 bits each");
 	__shared__ ZqShared sh;
-	const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x, K = d.K, lane = (int)lane_id();
+	__shared__ unsigned same_xcd;
+	if (xcd_pack && (blockIdx.x & 7)) return; /* every 8th block works: one XCD under round-robin placement */
+	const int t = threadIdx.x, g = xcd_pack ? blockIdx.x >> 3 : blockIdx.x, G = xcd_pack ? gridDim.x >> 3 : gridDim.x, K = d.K, lane = (int)lane_id();
 	const int W = (K + 2) / 3;
 	{
 		const uint16_t *src = (const uint16_t *)d.tab;
@@ -1510,6 +1553,7 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 		}
 	}
 	__syncthreads();
+	const bool local = xcd_pack && coop_same_xcd(cb, g, G, &same_xcd);
 	const isg_wh cur = isg_wh_jump(&sh.tab, base, 0);
 	unsigned long long off = 0;
 	const size_t rowb = (size_t)d.Lp * 2;
@@ -1640,7 +1684,7 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 #pragma unroll
 			for (int m = 0; m < KMAX; m++)
 				if (m < K && lane == m / 3) v |= (unsigned long long)(wcnt[m] & 0xffff) << (16 * (m % 3));
-			if (lane < W) st_agent(&cb->gran[slot][(g * (BLOCK / 64) + (t >> 6)) * W + lane], v);
+			if (lane < W) { if (local) st_xcd(&cb->gran[slot][(g * (BLOCK / 64) + (t >> 6)) * W + lane], v); else st_agent(&cb->gran[slot][(g * (BLOCK / 64) + (t >> 6)) * W + lane], v); }
 		} else {
 			if (lane == 0) {
 #pragma unroll
@@ -1653,7 +1697,7 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 #pragma unroll
 				for (int c3 = 0; c3 < 3; c3++)
 					if (3 * t + c3 < K) v |= (unsigned long long)(sh.hist[par][3 * t + c3] & 0xffff) << (16 * c3);
-				st_agent(&cb->gran[slot][g * W + t], v);
+				if (local) st_xcd(&cb->gran[slot][g * W + t], v); else st_agent(&cb->gran[slot][g * W + t], v);
 			}
 		}
 		if (j < d.Lp) *(unsigned short *)(d.z + (size_t)i * rowb + (size_t)j * 2) = (unsigned short)(z0 | (z1 << 8));
@@ -2060,6 +2104,8 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 		c->coop = (e && atoi(e) == 0) ? 0 : 1;
 		e = getenv("INSTRUCT_ZQ_SPEC");
 		c->spec = (e && atoi(e) == 0) ? 0 : 1;
+		e = getenv("INSTRUCT_ZQ_XCD"); /* experimental, off by default: measured gain at config 3 is within noise */
+		c->xcd = (e && atoi(e) == 1) ? 1 : 0;
 	}
 	DALLOC(d.cnt, int, (size_t)Lp * Amax * K);
 	DALLOC(d.qq, double, (size_t)N * K);
@@ -2402,8 +2448,10 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 		if (G > ISG_COOP_GMAX) G = ISG_COOP_GMAX;
 		CoopBuf *cb = (CoopBuf *)c->d_coop;
 		prof_begin(c);
-#define COOP_LAUNCH(KM) hipLaunchKernelGGL((k_zq_coop<KM>), dim3(G), dim3(256), 0, c->stream, c->d, base, init_flag, c->alpha, cb, c->d_pos)
-#define SPEC_LAUNCH(KM) hipLaunchKernelGGL((k_zq_spec<KM>), dim3(G), dim3(256), 0, c->stream, c->d, base, c->alpha, cb, c->d_pos)
+#define COOP_LAUNCH(KM) hipLaunchKernelGGL((k_zq_coop<KM>), dim3(pack ? 8 * G : G), dim3(256), 0, c->stream, c->d, base, init_flag, c->alpha, cb, c->d_pos, pack)
+		/* few enough workgroups for one XCD (32 CUs): start 8 G blocks, every 8th works (see coop_same_xcd) */
+		const int pack = (G <= 32 && c->xcd) ? 1 : 0;
+#define SPEC_LAUNCH(KM) hipLaunchKernelGGL((k_zq_spec<KM>), dim3(pack ? 8 * G : G), dim3(256), 0, c->stream, c->d, base, c->alpha, cb, c->d_pos, pack)
 		const bool spec = !init_flag && K <= 8 && G * 256 >= c->d.Lp && c->spec;
 		if (spec) {
 			switch (K) {
