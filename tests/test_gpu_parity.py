@@ -124,6 +124,28 @@ def test_edge_shapes_bit_exact_vs_canonical_oracle(case, sched):
     h.close()
 
 
+# replay update_ZQ kernel variants: the default picks k_zq_spec (K <= 8, one locus per lane) or k_zq_coop; the
+# environment switches force the other ones; all of them must give the oracle's state
+@pytest.mark.parametrize("env", [{}, {"INSTRUCT_ZQ_SPEC": "0"}, {"INSTRUCT_ZQ_XCD": "1"}, {"INSTRUCT_ZQ_SPEC": "0", "INSTRUCT_ZQ_XCD": "1"},
+                                 {"INSTRUCT_ZQ_COOP": "0"}])
+@pytest.mark.parametrize("case", [(24, 700, 5, 0.05, 2), (6, 40000, 3, 0.02, 2), (8, 33000, 9, 0.0, 3)])
+def test_replay_zq_kernel_variants_bit_exact_vs_canonical_oracle(case, env, monkeypatch):
+    """L > 32768: more loci than 128 workgroups x 256 lanes -> several passes per individual in the cooperative kernels"""
+    N, L, K, miss, nall = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    geno, an, mi = synth.code_diploid(synth.raw_alleles(N, L, K, 2, nall, miss, 23))
+    h, o, initd = _pair(geno, an, mi, K, capi.SCHED_REPLAY)
+    h.chain_init(initd)
+    o.chain_init(initd)
+    _same(h, o, ["z", "qq", "qqnum", "seeds"], "init")
+    for it in range(2):
+        h.iteration()
+        o.iteration()
+        _same(h, o, ["z", "qq", "qqnum", "generation", "alpha", "self_rates", "freq", "indvlkh", "totallkh", "seeds"], it)
+    h.close()
+
+
 def _counts_hash(cnt, an):
     K, L, A = cnt.shape
     mask = np.arange(A)[None, :] < an[:, None]
