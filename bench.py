@@ -118,6 +118,37 @@ def cpu_baseline(geno, K, seeds):
     return {"value": round(1.0 / dt, 6), "unit": "iterations/s", "cores": 1, "kind": "port", "sample": sample, "s_per_iter": dt}
 
 
+def concurrent_chains_leg(geno, an, mi, K, device, steps):
+    """Independent replay chains sharing ONE GPU (one host thread + one HIP stream per chain, seeds per chain as for
+    the multi-GPU runs): the replay update_ZQ kernel is latency bound on 20 of the 256 CUs, so chains overlap."""
+    import threading
+    res = {}
+    chains = []
+    for r in range(8):
+        h = capi.HipChain(geno, an, mi, K, rng_sched=capi.SCHED_REPLAY, device=device)
+        h.setseeds(*multichain.rank_seeds((13, 4, 1972), r))
+        h.chain_init(np.array([h.ran1() for _ in range(K)], dtype=np.float32))
+        h.run(1)
+        chains.append(h)
+
+    def work(h):
+        h.run(steps)
+        h.totallkh()
+    for n in (2, 8):
+        th = [threading.Thread(target=work, args=(h,)) for h in chains[:n]]
+        sync()
+        t0 = time.perf_counter()
+        [t.start() for t in th]
+        [t.join() for t in th]
+        sync()
+        dt = time.perf_counter() - t0
+        res[str(n)] = {"chain_iterations_per_s": round(n * steps / dt, 3), "ms_per_step_per_chain": round(dt / steps * 1e3, 3)}
+    for h in chains:
+        h.close()
+    res["note"] = "aggregate over n chains on one GPU, replay schedule; not part of `value` (1 chain per GPU)"
+    return res
+
+
 def tetra_leg(device, steps, warmup, with_cpu):
     """BASELINE.json config 5 on one GPU: N=10000 L=20000 K=10 ploidy 4 (autotetraploid), 5 % missing, replay
     schedule.  The synthetic population is 1000 distinct individuals x 10 replicas (the generator's numpy
@@ -254,6 +285,7 @@ def main():
                              "gelman_rubin": k["gelman_rubin"],
                              "note": "counter-based stream positions: bit-identical to the oracle's keyed schedule, statistically equivalent to the reference"}
         if world == 1 and not args.no_tetra:
+            line["concurrent_chains"] = concurrent_chains_leg(geno, an, mi, K, local, max(4, args.steps // 2))
             line["ploidy4"] = tetra_leg(local, max(2, args.steps // 4), 1, not args.no_cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
