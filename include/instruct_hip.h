@@ -75,6 +75,7 @@ int isg_update_alpha(isg_ctx *ctx);             /* mcmc.c:1244-1263 */
 int isg_cal_lkh(isg_ctx *ctx);                  /* mcmc.c:1916-1942 */
 int isg_iteration(isg_ctx *ctx);                /* the loop body mcmc.c:210-215 (mode 2) / 152-155 (mode 1) */
 int isg_run(isg_ctx *ctx, long n_iterations);
+int isg_iter_advance(isg_ctx *ctx);             /* sweep-by-sweep drivers: counts an iteration (keyed positions depend on it) */
 
 /* allele counts seqpop[K][L][Amax] of the current Z (the count nest mcmc.c:810-845) */
 int isg_count_alleles(isg_ctx *ctx, int32_t *counts);

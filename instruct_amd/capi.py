@@ -19,7 +19,7 @@ SCHED_REPLAY, SCHED_KEYED = 0, 1
 EXPORTS = [
     "isg_ctx_create", "isg_ctx_destroy", "isg_last_error", "isg_set_seeds", "isg_get_seeds", "isg_ran1",
     "isg_chain_init", "isg_update_P", "isg_update_S_POP", "isg_update_G", "isg_update_ZQ", "isg_update_alpha",
-    "isg_cal_lkh", "isg_iteration", "isg_run", "isg_count_alleles", "isg_get_z", "isg_get_freq", "isg_get_qq",
+    "isg_cal_lkh", "isg_iteration", "isg_run", "isg_iter_advance", "isg_count_alleles", "isg_get_z", "isg_get_freq", "isg_get_qq",
     "isg_get_qqnum", "isg_get_generation", "isg_get_self_rates", "isg_get_state", "isg_get_indvlkh",
     "isg_get_alpha", "isg_get_totallkh", "isg_get_amax", "isg_set_z", "isg_set_freq", "isg_set_qq",
     "isg_set_generation", "isg_set_self_rates", "isg_set_alpha", "isg_keyed_layout", "isg_profile_enable",
@@ -228,14 +228,14 @@ class HipPolyChain(HipChain):
     (0 = missing) -- SEQDATA.seqdata / SEQDATA.alleleid as transform_data2 (data_interface.c:571-669) leaves them.
     """
 
-    def __init__(self, obs, alleleid, allelenum, K, back_refl=1, device=0):
+    def __init__(self, obs, alleleid, allelenum, K, back_refl=1, rng_sched=SCHED_REPLAY, device=0):
         self.lib = load()
         obs = np.ascontiguousarray(obs, dtype=np.int32)
         self.N, self.L, self.P = obs.shape
         self.K = K
         allelenum = np.ascontiguousarray(allelenum, dtype=np.int32)
         alleleid = np.ascontiguousarray(alleleid, dtype=np.int32)
-        cfg = IsgConfig(self.N, self.L, self.P, K, 2, 1, back_refl, SCHED_REPLAY, device)
+        cfg = IsgConfig(self.N, self.L, self.P, K, 2, 1, back_refl, rng_sched, device)
         h = C.c_void_p()
         self._chk(self.lib.isg_ctx_create_poly(C.byref(cfg), _ptr(allelenum), _ptr(obs), _ptr(alleleid), C.byref(h)))
         self.h = h

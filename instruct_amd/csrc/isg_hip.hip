@@ -2663,7 +2663,7 @@ extern "C" int isg_set_z(isg_ctx *c, const int32_t *z)
 extern "C" int isg_get_freq(isg_ctx *c, double *f)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
-	if (c->poly) { memcpy(f, c->freq.data(), sizeof(double) * c->freq.size()); return 0; } /* the host draws them */
+	if (c->poly && c->poly->freq_host) { memcpy(f, c->freq.data(), sizeof(double) * c->freq.size()); return 0; } /* drawn on the host */
 	if (download_freq(c)) return 1;
 	memcpy(f, c->freq.data(), sizeof(double) * c->freq.size());
 	return 0;

@@ -18,6 +18,7 @@
 #include <ctype.h>
 #include "dump_fmt.h"
 #include "isg_math.h"
+#include "isg_wh.h"
 /* genotype-class tables: the shared template (instruct_amd/csrc/isg_poly_tables.h) instantiated twice --
  * with glibc (the reference configuration pinned to the golden files) and with the canonical math */
 #define PT_NAME(x) ptl_##x
@@ -51,6 +52,20 @@ static double sum_val(const summer *s) { return g_accum ? isg_acc_value(&s->a) :
 
 /* ------------------------------------------------------------------ RNG + samplers (random.c) */
 static long sd1 = 13, sd2 = 4, sd3 = 1972;
+/* keyed schedule (third switch; same samplers, same generator): every consumer first seeks to a stream position
+ * that depends only on (iteration, phase, index), counted from the chain origin -- layout in
+ * include/instruct_hip.h.  Off = the reference's sequential consumption. */
+static int g_keyed;
+static isg_wh g_origin;
+static isg_wh_tables g_tab;
+static uint64_t ky_SP, ky_SZ, ky_G0, ky_ZI0, ky_B0, ky_offS, ky_offZ, ky_offGE, ky_BLK, ky_iter;
+static void rng_seek(uint64_t pos)
+{
+	isg_wh s;
+	if (!g_keyed) return;
+	s = isg_wh_jump(&g_tab, g_origin, pos);
+	sd1 = s.s1; sd2 = s.s2; sd3 = s.s3;
+}
 static double ran1(void)
 {
 	sd1 = (171 * sd1) % 30269;
@@ -204,6 +219,7 @@ static int choose_unif(int temp) /* poly_geno.c:840-852 */
 static void initial_geno(void) /* poly_geno.c:316-369 (autopoly) */
 {
 	int i, j, k;
+	rng_seek(ky_G0);
 	for (i = 0; i < N; i++)
 		for (j = 0; j < L; j++) {
 			if (!VALID(i, j)) continue;
@@ -228,6 +244,7 @@ static void update_P_auto(void) /* poly_geno.c:390-438 */
 	for (i = 0; i < K; i++)
 		for (j = 0; j < L; j++) {
 			for (k = 0; k < allelenum[j]; k++) tmp[k] = (double)cnt[((long)i * L + j) * Amax + k];
+			rng_seek(ky_B0 + ky_iter * ky_BLK + ((uint64_t)i * L + j) * ky_SP);
 			rdirich(tmp, allelenum[j], &FREQ(i, j, 0), 1.0);
 		}
 	free(cnt);
@@ -405,6 +422,7 @@ static void update_S_POP(void) /* poly_geno.c:584-643 */
 	float **tab = malloc(sizeof(float *) * L);
 	for (i = 0; i < L; i++) tab[i] = malloc(sizeof(float) * gtot(i));
 	for (j = 0; j < K; j++) calc_self_genofreq(S[j], genofreq, j, 1);
+	rng_seek(ky_B0 + ky_iter * ky_BLK + ky_offS);
 	for (j = 0; j < K; j++) {
 		if (back_refl == 1) {
 			tmp = ran1() * 2 * delta0 - delta0;
@@ -439,6 +457,7 @@ static void update_ZQ(int init_flag) /* poly_geno.c:750-836 */
 	int i, j, k, m;
 	double *tmp = malloc(sizeof(double) * K);
 	for (i = 0; i < N; i++) {
+		rng_seek(init_flag == 1 ? ky_ZI0 + (uint64_t)i * ky_SZ : ky_B0 + ky_iter * ky_BLK + ky_offZ + (uint64_t)i * ky_SZ);
 		for (j = 0; j < L; j++)
 			if (VALID(i, j))
 				for (k = 0; k < P4; k++) {
@@ -500,6 +519,7 @@ static int choose_auto(int i, int j, int n_type) /* choose_two_auto / choose_tri
 static void update_geno(void) /* poly_geno.c:520-580 (autopoly); the canonical-order fix-up never fires for -ap 1 */
 {
 	int i, j, k;
+	rng_seek(ky_B0 + ky_iter * ky_BLK + ky_offGE);
 	for (i = 0; i < N; i++)
 		for (j = 0; j < L; j++) {
 			if (!VALID(i, j)) continue;
@@ -598,8 +618,9 @@ int main(int argc, char **argv)
 	double c_tot = 1, c_tot2 = 1, *c_indv, *c_S, *c_qq;
 	long c_step = 0, steps;
 	int flag_empty = 0;
-	if (argc != 15 && argc != 17) { fprintf(stderr, "usage: orc_dump_poly data out K N L u b t e r j s1 s2 s3 [math accum]\n"); return 2; }
-	if (argc == 17) { g_math = atoi(argv[15]); g_accum = atoi(argv[16]); }
+	if (argc != 15 && argc != 17 && argc != 18) { fprintf(stderr, "usage: orc_dump_poly data out K N L u b t e r j s1 s2 s3 [math accum [keyed]]\n"); return 2; }
+	if (argc >= 17) { g_math = atoi(argv[15]); g_accum = atoi(argv[16]); }
+	if (argc == 18) g_keyed = atoi(argv[17]);
 	K = atoi(argv[3]); u = atol(argv[6]); b = atol(argv[7]); t = atoi(argv[8]); e = atoi(argv[9]); r = atoi(argv[10]); jj = atoi(argv[11]);
 	s1 = atoi(argv[12]); s2 = atoi(argv[13]); s3 = atoi(argv[14]);
 	back_refl = e;
@@ -630,6 +651,16 @@ int main(int argc, char **argv)
 #define SEEDS() fprintf(G, " seeds=%ld %ld %ld\n", sd1, sd2, sd3)
 #define GFLAT() do { for (i = 0; i < N; i++) for (j = 0; j < L; j++) for (k = 0; k < P4; k++) gflat[((long)i * L + j) * P4 + k] = VALID(i, j) ? GENO(i, j, k) : -1; } while (0)
 	gen_polyinfo();
+	{ /* keyed layout; the chain origin is the stream state when the chain starts (after read_init's draws) */
+		uint64_t amb = 0;
+		for (i = 0; i < N * L; i++) amb += (alleleid[i] == 2 || alleleid[i] == 3);
+		isg_wh_tables_init(&g_tab);
+		g_origin.s1 = (uint32_t)sd1; g_origin.s2 = (uint32_t)sd2; g_origin.s3 = (uint32_t)sd3;
+		ky_SP = 16 * (uint64_t)Amax + 16; ky_SZ = 4 * (uint64_t)L + 16 * (uint64_t)K + 16;
+		ky_G0 = 1; ky_ZI0 = 1 + amb; ky_B0 = ky_ZI0 + (uint64_t)N * ky_SZ;
+		ky_offS = (uint64_t)K * L * ky_SP; ky_offZ = ky_offS + 4 * (uint64_t)K; ky_offGE = ky_offZ + (uint64_t)N * ky_SZ;
+		ky_BLK = ky_offGE + amb + 4;
+	}
 	alpha = ran1() * 10;
 	fprintf(G, "chain init alpha=%a", alpha); SEEDS();
 	initial_geno();
@@ -639,6 +670,7 @@ int main(int argc, char **argv)
 	update_ZQ(1);
 	fprintf(G, "chain zqinit hz=%016llx hqq=%016llx", (unsigned long long)hash_z(&D, z), (unsigned long long)hash_f64v(qq, (long)N * K)); SEEDS();
 	for (step = 0; step < u; step++) {
+		ky_iter = (uint64_t)step;
 		update_P_auto();
 		GFLAT();
 		count_alleles_plain(&D, gflat, z, cflat);

@@ -35,12 +35,12 @@ def extra_data(name):
     return synth.raw_alleles(N, L, K, 4, A, miss, 20260301 + sorted(EXTRA).index(name))
 
 
-def hip_lines(name, cfg=None, raw=None):
+def hip_lines(name, cfg=None, raw=None, sched=0):
     """Drives the C ABI sweep by sweep and formats the state as oracle/isg_oracle_poly.c's dump does."""
     from instruct_amd import capi, synth
     N, L, K, A, miss, u, b, t, e, r, j, seeds = cfg or POLY[name]
     obs, alleleid, allelenum = synth.code_tetraploid(raw if raw is not None else gu.make_golden.poly_data_for(name))
-    ch = capi.HipPolyChain(obs, alleleid, allelenum, K, back_refl=e)
+    ch = capi.HipPolyChain(obs, alleleid, allelenum, K, back_refl=e, rng_sched=sched)
     ch.setseeds(*seeds)
     initd = np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32)
     lines = []
@@ -63,6 +63,7 @@ def hip_lines(name, cfg=None, raw=None):
         lines.append("it %d GE hgeno=%s" % (step, orc.fnv_i32(ch.geno())) + sd())
         ch.cal_lkh()
         lines.append("it %d L totallkh=%s hindv=%s" % (step, float(ch.totallkh()).hex(), orc.fnv_f64(ch.indvlkh())))
+        ch.lib.isg_iter_advance(ch.h)   # sweep-by-sweep drivers count the iterations themselves (keyed positions)
     ch.close()
     return lines
 
@@ -117,20 +118,42 @@ def test_tetraploid_single_workgroup_zq_kernel_gives_the_same_lines(monkeypatch)
     assert hip_lines("t1") == coop
 
 
+def _noseeds(line):
+    return line.split(" seeds=")[0]
+
+
+@pytest.mark.parametrize("sched", [0, 1])
 @pytest.mark.parametrize("name", sorted(EXTRA))
-def test_tetraploid_generated_cases_bit_identical_to_canonical_oracle(name, tmp_path):
+def test_tetraploid_generated_cases_bit_identical_to_canonical_oracle(name, sched, tmp_path):
+    """sched 1 = keyed schedule (every consumer seeks to its own stream position; the sequential seed triple is
+    not defined there and is left out of the comparison)"""
     from instruct_amd import synth
     N, L, K, A, miss, u, b, t, e, r, j, seeds = EXTRA[name]
     raw = extra_data(name)
     txt, out = str(tmp_path / (name + ".txt")), str(tmp_path / (name + ".can"))
     synth.write_text_polyploid(txt, raw)
-    args = [DUMP, txt, out] + [str(x) for x in (K, N, L, u, b, t, e, r, j) + tuple(seeds)] + ["1", "1"]
+    args = [DUMP, txt, out] + [str(x) for x in (K, N, L, u, b, t, e, r, j) + tuple(seeds)] + ["1", "1"] + (["1"] if sched else [])
     assert subprocess.call(args) == 0
     want = [l for l in gu.parse(out) if l.startswith("it ") or l.startswith("chain zqinit")]
-    got = hip_lines(name, EXTRA[name], raw)
+    got = hip_lines(name, EXTRA[name], raw, sched)
     assert len(got) == len(want) and len(got) == 1 + 6 * u
     for g, w in zip(got, want):
+        if sched:
+            g, w = _noseeds(g), _noseeds(w)
         assert _norm(g) == _norm(w)
+
+
+@pytest.mark.parametrize("name", sorted(POLY))
+def test_tetraploid_keyed_schedule_bit_identical_to_oracle_keyed(name, tmp_path):
+    N, L, K, A, miss, u, b, t, e, r, j, seeds = POLY[name]
+    out = str(tmp_path / (name + ".key"))
+    args = [DUMP, os.path.join(gu.GOLDEN, name + ".txt"), out] + [str(x) for x in (K, N, L, u, b, t, e, r, j) + tuple(seeds)] + ["1", "1", "1"]
+    assert subprocess.call(args) == 0
+    want = [l for l in gu.parse(out) if l.startswith("it ") or l.startswith("chain zqinit")]
+    got = hip_lines(name, sched=1)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert _norm(_noseeds(g)) == _norm(_noseeds(w))
 
 
 @pytest.mark.parametrize("name", sorted(POLY))

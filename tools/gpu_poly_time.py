@@ -9,6 +9,7 @@ from instruct_amd import capi, synth
 
 N, L, K, A = (int(x) for x in sys.argv[1:5])
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+sched = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 base = min(N, 1000)
 t = time.time()
 raw = synth.raw_alleles(base, L, K, 4, A, 0.05, 20260105)
@@ -18,7 +19,7 @@ if N > base:
     obs, alleleid = np.tile(obs, (rep, 1, 1)), np.tile(alleleid, (rep, 1))
 print("data %.1fs" % (time.time() - t), obs.shape, flush=True)
 t = time.time()
-ch = capi.HipPolyChain(obs, alleleid, allelenum, K)
+ch = capi.HipPolyChain(obs, alleleid, allelenum, K, rng_sched=sched)
 print("ctx %.1fs" % (time.time() - t), flush=True)
 ch.setseeds(13, 4, 1972)
 initd = np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32)
