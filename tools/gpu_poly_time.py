@@ -23,6 +23,7 @@ ch = capi.HipPolyChain(obs, alleleid, allelenum, K, rng_sched=sched)
 print("ctx %.1fs" % (time.time() - t), flush=True)
 ch.setseeds(13, 4, 1972)
 initd = np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32)
+ch.profile(True)
 t = time.time()
 ch.chain_init(initd)
 print("init %.2fs" % (time.time() - t), flush=True)
