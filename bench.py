@@ -157,28 +157,35 @@ def tetra_leg(device, steps, warmup, with_cpu):
     raw = synth.raw_alleles(base, L, K, 4, A, 0.05, 20260105)
     obs, alleleid, allelenum = synth.code_tetraploid_fast(raw)
     obs, alleleid = np.tile(obs, (N // base, 1, 1)), np.tile(alleleid, (N // base, 1))
-    ch = capi.HipPolyChain(obs, alleleid, allelenum, K, back_refl=1, device=device)
-    ch.setseeds(13, 4, 1972)
-    ch.chain_init(np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32))
-    ch.run(warmup)
-    ch.profile_reset()
-    ch.profile(True)
-    sync()
-    t0 = time.perf_counter()
-    ch.run(steps)
-    last = ch.totallkh()
-    sync()
-    dt = time.perf_counter() - t0
-    ch.profile(False)
-    prof = ch.profile_results()
-    ch.close()
     nvalid = int((alleleid > 0).sum())
-    zq = "k4_zq_coop" if "k4_zq_coop" in prof else "k4_zq"
-    res = {"workload": "config5: N=10000 L=20000 K=10 ploidy 4 (-p 4 -ap 1), 5% missing, 1 chain, replay schedule",
-           "value": round(steps / dt, 4), "unit": "iterations/s", "ms_per_step": round(dt / steps * 1e3, 3),
-           "roofline": roofline(prof, zq, 2 * 4 * nvalid + 8 * 4 * nvalid, None),  # genotype + Z byte per copy, one tape double per copy
-           "kernels_ms": {k: round(ms / n, 4) for k, (ms, n) in sorted(prof.items())},
-           "iteration_frac_of_hbm": round(5 * N * L * 4 / (dt / steps) / 1e9 / HBM_PEAK_GBS, 6), "last_totallkh": last}
+    traffic = load_traffic()
+
+    def one(sched, nsteps):
+        ch = capi.HipPolyChain(obs, alleleid, allelenum, K, back_refl=1, rng_sched=sched, device=device)
+        ch.setseeds(13, 4, 1972)
+        ch.chain_init(np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32))
+        ch.run(warmup)
+        ch.profile_reset()
+        ch.profile(True)
+        sync()
+        t0 = time.perf_counter()
+        ch.run(nsteps)
+        last = ch.totallkh()
+        sync()
+        dt = time.perf_counter() - t0
+        ch.profile(False)
+        prof = ch.profile_results()
+        ch.close()
+        zq = next(k for k in ("k4_zq_coop", "k4_zq_keyed", "k4_zq") if k in prof)
+        # update_ZQ launch: genotype + Z byte per copy (+ one tape double per copy in the replay schedule)
+        alg = 2 * 4 * nvalid + (8 * 4 * nvalid if sched == capi.SCHED_REPLAY else 0)
+        return {"value": round(nsteps / dt, 4), "unit": "iterations/s", "ms_per_step": round(dt / nsteps * 1e3, 3),
+                "roofline": roofline(prof, zq, alg, traffic.get(zq)),
+                "kernels_ms": {k: round(ms / n, 4) for k, (ms, n) in sorted(prof.items())},
+                "iteration_frac_of_hbm": round(5 * N * L * 4 / (dt / nsteps) / 1e9 / HBM_PEAK_GBS, 6), "last_totallkh": last}
+    res = {"workload": "config5: N=10000 L=20000 K=10 ploidy 4 (-p 4 -ap 1), 5% missing, 1 chain; value = replay schedule"}
+    res.update(one(capi.SCHED_REPLAY, steps))
+    res["keyed"] = one(capi.SCHED_KEYED, 4 * steps)
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump_poly")
     if with_cpu and os.path.exists(exe):
         # the reference's own ploidy-4 chain (poly_geno.c) on one host core at 1/400 of the allele copies; the
@@ -199,6 +206,7 @@ def tetra_leg(device, steps, warmup, with_cpu):
                                "sample": f"reference poly_geno.c chain at N={n} L={l} K={K} ({s_small:.3f} s/iteration), scaled by N*L = x{scale:.0f} (every sweep is linear in N*L)",
                                "s_per_iter_extrapolated": round(s_small * scale, 1)}
         res["speedup_vs_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        res["keyed"]["speedup_vs_cpu"] = round(res["keyed"]["value"] / res["cpu_baseline"]["value"], 1)
     return res
 
 
