@@ -613,13 +613,10 @@ struct ZqShared {
  * Returns (for every thread) the number of uniforms consumed.
  */
 template <int BLOCK, int KMAX>
-__device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &sh, int i, isg_wh dstart, double alpha, int par,
-						   const double *dtape = nullptr, unsigned long long *pub = nullptr,
-						   unsigned long long pub_base = 0, unsigned long long pub_tag = 0,
-						   unsigned long long dstart_off = 0)
+__device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &sh, int i, isg_wh dstart, double alpha, int par)
 {
-	/* the generator state at the Dirichlet's first position is jump(dstart, dstart_off): the cooperative
-	 * kernel keeps only the offset from the start of the phase while the tape covers the draws */
+	const double *dtape = nullptr; /* (the cooperative kernels read their uniforms from the tape: dirichlet_coop) */
+	const unsigned long long dstart_off = 0;
 	const int K = d.K, t = threadIdx.x;
 	int *hist = sh.hist[par];
 	int noff = BLOCK / K;
@@ -691,9 +688,6 @@ __device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &
 				off += c.used;
 			}
 			sh.used_total = off;
-			/* cooperative kernel: the next individual's offset leaves as soon as it is known */
-			if (pub) __hip_atomic_store(pub, (pub_tag << 48) | (pub_base + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			STAMP(i, 5);
 		}
 	}
 	lds_barrier();
@@ -1000,14 +994,14 @@ __global__ void __launch_bounds__(BLOCK) k_zq(DevView d, isg_wh base, uint64_t p
  * In the replay schedule individual i+1 starts where individual i's Dirichlet stopped, so the
  * individuals are processed in order; what CAN be spread out is one individual's loci.  G workgroups
  * (one locus per lane) all work on the same individual: each draws the Z of its loci from the uniform
- * tape at the individual's start offset, counts its buckets and hands the counts to workgroup 0, which
- * adds them up, draws the Dirichlet and publishes the next individual's offset.
+ * tape at the individual's start offset, counts its buckets and publishes the counts; every workgroup
+ * collects all of them and draws the Dirichlet itself (same inputs, same consumption), so each knows where
+ * the next individual starts without being told: one exchange per individual.
  *
  * Hand-offs are single naturally aligned 8-byte words that carry their own tag (16 bits derived from
  * the individual's index), written with one agent-scope store and polled with agent-scope loads
  * (MI355X_MICROARCH.md, "data-tagged granules"): no separate flag, no fence ordering to get wrong.
- *   pos[slot]        = offset(48) | tag(16)                      workgroup 0 -> everyone
- *   gran[slot][g][w] = counts 3w..3w+2 (16 bits each) | tag(16)  workgroup g -> workgroup 0
+ *   gran[slot][g][w] = counts 3w..3w+2 (16 bits each) | tag(16)  workgroup (or wave) g -> everybody
  * Nobody runs more than one individual ahead of anybody else (the next offset needs everybody's
  * counts), so a ring of 4 slots suffices.  Every spin is bounded and watches a common abort word.
  */
@@ -1015,7 +1009,6 @@ __global__ void __launch_bounds__(BLOCK) k_zq(DevView d, isg_wh base, uint64_t p
 #define ISG_COOP_GMAX 128
 #define ISG_COOP_WMAX 11
 struct CoopBuf {
-	unsigned long long pos[ISG_COOP_RING];
 	unsigned long long gran[ISG_COOP_RING][ISG_COOP_GMAX * ISG_COOP_WMAX];
 	unsigned abort_flag;
 	unsigned overflow_flag;
@@ -1047,28 +1040,6 @@ __device__ __forceinline__ unsigned xcc_id()
  * hardware register.)  One tagged agent-scope word per workgroup, everybody reads all of them.
  */
 __device__ __forceinline__ bool coop_same_xcd(CoopBuf *cb, int g, int G, unsigned *lds_flag);
-/* lane 0 of the calling wave polls *p until its top 16 bits equal tag; the word is returned to all lanes */
-__device__ __forceinline__ unsigned long long coop_wait(const unsigned long long *p, unsigned tag, CoopBuf *cb)
-{
-	unsigned long long v = 0;
-	if (lane_id() == 0) {
-		for (unsigned spin = 0;; spin++) {
-			v = ld_agent(p);
-			if ((unsigned)(v >> 48) == tag) break;
-			if ((spin & 1023u) == 1023u) {
-				if (__hip_atomic_load(&cb->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-				if (spin > (1u << 24)) { /* ~ seconds: somebody is stuck; release everyone */
-					__hip_atomic_store(&cb->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					break;
-				}
-			}
-			__builtin_amdgcn_s_sleep(1);
-		}
-	}
-	unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-	return ((unsigned long long)hi << 32) | lo;
-}
-
 /*
  * isg_rgamma2_try (random.c:195-231) for the cooperative kernels' critical path.  The two logarithms only feed the
  * accept / reject decision  c3 log(u1) - log(w) + w >= 1 ; evaluated with single precision logarithms the sign of
@@ -1121,7 +1092,7 @@ __device__ __forceinline__ double rgamma2_try_dev(isg_cursor *c, double pu0, dou
 	return c1 * w;
 }
 
-/* lane `l` of the calling wave polls granule *p until it carries `tag` (bounded; see coop_wait) */
+/* the calling lane polls granule *p until it carries `tag`; every spin is bounded and watches the common abort word */
 __device__ __forceinline__ unsigned long long coop_poll(const unsigned long long *p, unsigned tag, CoopBuf *cb)
 {
 	unsigned long long v = 0;
