@@ -734,28 +734,43 @@ __device__ __forceinline__ void zq_prefetch(const DevView &d, int i, int init_fl
  * `amb` is raised and the caller redoes THIS draw in double (bucket_fast), so the returned Z is always
  * the reference's.  About 5 draws in 100000 are redone.
  */
+/* bucket_f32 split in two: the running sums of a copy (position independent) and the comparison of one uniform */
 template <int KMAX>
-__device__ __forceinline__ int bucket_f32(float xf, const float (&F)[KMAX], const float (&qf)[KMAX], int K, bool *amb)
+__device__ __forceinline__ float prefix_f32(const float (&F)[KMAX], const float (&qf)[KMAX], int K, float (&cum)[KMAX])
 {
-	float cum[KMAX], run = 0.f;
+	float run = 0.f;
 #pragma unroll
 	for (int m = 0; m < KMAX; m++) {
 		if (m < K) run = (m == 0) ? qf[m] * F[m] : run + qf[m] * F[m];
 		cum[m] = run;
 	}
+	return run;
+}
+/* same decision as bucket_f32: the guard band test |dd| <= marg for any m is  !(min |dd| > marg) */
+template <int KMAX>
+__device__ __forceinline__ int bucket_from_cum(float xf, const float (&cum)[KMAX], float run, int K, bool *amb)
+{
 	const float p = xf * run, marg = 6e-6f * run;
-	bool a = !(run > 1e-30f && run < 1e30f) || !(xf > 4e-6f && xf < 1.0f - 4e-6f);
+	float mn = 3.0e38f;
 	int z = 0;
 #pragma unroll
 	for (int m = 0; m < KMAX - 1; m++) {
 		if (m < K - 1) {
 			const float dd = p - cum[m];
 			z += (dd > 0.f) ? 1 : 0;
-			a |= !(dd > marg || dd < -marg);
+			mn = __builtin_fminf(mn, __builtin_fabsf(dd));
 		}
 	}
-	*amb = a;
+	*amb = !(mn > marg) || !(run > 1e-30f && run < 1e30f) || !(xf > 4e-6f && xf < 1.0f - 4e-6f);
 	return z;
+}
+
+template <int KMAX>
+__device__ __forceinline__ int bucket_f32(float xf, const float (&F)[KMAX], const float (&qf)[KMAX], int K, bool *amb)
+{
+	float cum[KMAX];
+	const float run = prefix_f32<KMAX>(F, qf, K, cum);
+	return bucket_from_cum<KMAX>(xf, cum, run, K, amb);
 }
 
 /* Z draws of one individual; `cur` = stream state at its first position, `off` = that position counted
@@ -1258,7 +1273,6 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 	__shared__ unsigned same_xcd;
 	if (xcd_pack && (blockIdx.x & 7)) return; /* every 8th block works: one XCD under round-robin placement */
 	const int t = threadIdx.x, g = xcd_pack ? blockIdx.x >> 3 : blockIdx.x, G = xcd_pack ? gridDim.x >> 3 : gridDim.x, K = d.K;
-	const int W = (K + 2) / 3;
 	{
 		const uint16_t *src = (const uint16_t *)d.tab;
 		uint16_t *dst = (uint16_t *)&sh.tab;
@@ -1277,7 +1291,10 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 	const int stride = G * BLOCK;
 	const size_t rowb = (size_t)d.Lp * 2;
 	const bool writer = (g == 0) && (t >= BLOCK - 64);
-	const bool wmode = (G * (BLOCK / 64) * W <= BLOCK); /* one polling round covers a granule per wave */
+	const bool wmode = (G * (BLOCK / 64) * ((K + 2) / 3) <= BLOCK); /* one polling round covers a granule per wave */
+	/* counts per exchanged word: 3 x 16 bits, or 4 x 12 bits when a workgroup's count of one bucket stays below 4096 */
+	const int npass = (d.Lp + G * BLOCK - 1) / (G * BLOCK);
+	const int pack = (!wmode && 2 * BLOCK * npass < 4096) ? 4 : 3, bits = (pack == 4) ? 12 : 16, W = (K + pack - 1) / pack;
 	double icum[KMAX];
 #pragma unroll
 	for (int m = 0; m < KMAX; m++) icum[m] = (m < K) ? (double)(m + 1) / K : 0.0; /* mcmc.c:1144 */
@@ -1417,11 +1434,10 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 			}
 			lds_barrier();
 			/* this workgroup's counts leave; everybody else's are collected */
-			if (t < W) {
+			if (t < W) { /* `pack` counts of `bits` bits per word */
 				unsigned long long v = (unsigned long long)tag << 48;
-#pragma unroll
-				for (int c3 = 0; c3 < 3; c3++)
-					if (3 * t + c3 < K) v |= (unsigned long long)(sh.hist[par][3 * t + c3] & 0xffff) << (16 * c3);
+				for (int c3 = 0; c3 < pack; c3++)
+					if (pack * t + c3 < K) v |= (unsigned long long)(sh.hist[par][pack * t + c3] & ((1 << bits) - 1)) << (bits * c3);
 				if (local) st_xcd(&cb->gran[slot][g * W + t], v); else st_agent(&cb->gran[slot][g * W + t], v);
 			}
 		}
@@ -1439,10 +1455,9 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 			if (gi < ngran && (wmode || gi / W != g)) {
 				const unsigned long long v = coop_poll(&cb->gran[slot][gi], tag, cb);
 				const int w = gi % W;
-#pragma unroll
-				for (int c3 = 0; c3 < 3; c3++) {
-					const int m = 3 * w + c3;
-					const int c = (int)((v >> (16 * c3)) & 0xffff);
+				for (int c3 = 0; c3 < pack; c3++) {
+					const int m = pack * w + c3;
+					const int c = (int)((v >> (bits * c3)) & ((1 << bits) - 1));
 					if (m < K && c) atomicAdd(&sh.ghist[par][m], c);
 				}
 			}
@@ -1457,37 +1472,6 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 		off += used;
 	}
 	if (g == 0 && t == 0) *pos_out = off;
-}
-
-/* bucket_f32 split in two: the running sums of a copy (position independent) and the comparison of one uniform */
-template <int KMAX>
-__device__ __forceinline__ float prefix_f32(const float (&F)[KMAX], const float (&qf)[KMAX], int K, float (&cum)[KMAX])
-{
-	float run = 0.f;
-#pragma unroll
-	for (int m = 0; m < KMAX; m++) {
-		if (m < K) run = (m == 0) ? qf[m] * F[m] : run + qf[m] * F[m];
-		cum[m] = run;
-	}
-	return run;
-}
-/* same decision as bucket_f32: the guard band test |dd| <= marg for any m is  !(min |dd| > marg) */
-template <int KMAX>
-__device__ __forceinline__ int bucket_from_cum(float xf, const float (&cum)[KMAX], float run, int K, bool *amb)
-{
-	const float p = xf * run, marg = 6e-6f * run;
-	float mn = 3.0e38f;
-	int z = 0;
-#pragma unroll
-	for (int m = 0; m < KMAX - 1; m++) {
-		if (m < K - 1) {
-			const float dd = p - cum[m];
-			z += (dd > 0.f) ? 1 : 0;
-			mn = __builtin_fminf(mn, __builtin_fabsf(dd));
-		}
-	}
-	*amb = !(mn > marg) || !(run > 1e-30f && run < 1e30f) || !(xf > 4e-6f && xf < 1.0f - 4e-6f);
-	return z;
 }
 
 /*
@@ -1511,7 +1495,6 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 	__shared__ unsigned same_xcd;
 	if (xcd_pack && (blockIdx.x & 7)) return; /* every 8th block works: one XCD under round-robin placement */
 	const int t = threadIdx.x, g = xcd_pack ? blockIdx.x >> 3 : blockIdx.x, G = xcd_pack ? gridDim.x >> 3 : gridDim.x, K = d.K, lane = (int)lane_id();
-	const int W = (K + 2) / 3;
 	{
 		const uint16_t *src = (const uint16_t *)d.tab;
 		uint16_t *dst = (uint16_t *)&sh.tab;
@@ -1529,7 +1512,10 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 	unsigned long long off = 0;
 	const size_t rowb = (size_t)d.Lp * 2;
 	const bool writer = (g == 0) && (t >= BLOCK - 64);
-	const bool wmode = (G * (BLOCK / 64) * W <= BLOCK);
+	const bool wmode = (G * (BLOCK / 64) * ((K + 2) / 3) <= BLOCK);
+	/* counts per exchanged word: 3 x 16 bits, or 4 x 12 bits when a workgroup's count of one bucket stays below 4096 */
+	const int npass = (d.Lp + G * BLOCK - 1) / (G * BLOCK);
+	const int pack = (!wmode && 2 * BLOCK * npass < 4096) ? 4 : 3, bits = (pack == 4) ? 12 : 16, W = (K + pack - 1) / pack;
 	const int j = g * BLOCK + t; /* this lane's locus */
 	double touch = 0.0;
 	/* three individuals in flight per lane: cl = the one being finished, nl = the one whose candidates are drawn,
@@ -1663,11 +1649,10 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 					if (m < K && wcnt[m]) atomicAdd(&sh.hist[par][m], wcnt[m]);
 			}
 			lds_barrier();
-			if (t < W) {
+			if (t < W) { /* `pack` counts of `bits` bits per word */
 				unsigned long long v = (unsigned long long)tag << 48;
-#pragma unroll
-				for (int c3 = 0; c3 < 3; c3++)
-					if (3 * t + c3 < K) v |= (unsigned long long)(sh.hist[par][3 * t + c3] & 0xffff) << (16 * c3);
+				for (int c3 = 0; c3 < pack; c3++)
+					if (pack * t + c3 < K) v |= (unsigned long long)(sh.hist[par][pack * t + c3] & ((1 << bits) - 1)) << (bits * c3);
 				if (local) st_xcd(&cb->gran[slot][g * W + t], v); else st_agent(&cb->gran[slot][g * W + t], v);
 			}
 		}
@@ -1703,10 +1688,9 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 			if (gi < ngran && (wmode || gi / W != g)) {
 				const unsigned long long v = coop_poll(&cb->gran[slot][gi], tag, cb);
 				const int w = gi % W;
-#pragma unroll
-				for (int c3 = 0; c3 < 3; c3++) {
-					const int m = 3 * w + c3;
-					const int c = (int)((v >> (16 * c3)) & 0xffff);
+				for (int c3 = 0; c3 < pack; c3++) {
+					const int m = pack * w + c3;
+					const int c = (int)((v >> (bits * c3)) & ((1 << bits) - 1));
 					if (m < K && c) atomicAdd(&sh.ghist[par][m], c);
 				}
 			}

@@ -10,15 +10,31 @@ subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-
 from instruct_amd import capi, synth
 capi.LIB_PATH = diag
 N, L, K = int(sys.argv[1]), int(sys.argv[2]), 5
-geno, an, mi = synth.make_diploid(N, L, K)
-h = capi.HipChain(geno, an, mi, K)
-h.setseeds(13, 4, 1972)
-h.chain_init(np.array([h.ran1() for _ in range(K)], dtype=np.float32))
+tetra = "tetra" in sys.argv
+if tetra:
+    K = 10
+    raw = synth.raw_alleles(min(N, 1000), L, K, 4, 4, 0.05, 20260105)
+    obs, alleleid, allelenum = synth.code_tetraploid_fast(raw)
+    if N > 1000:
+        obs, alleleid = np.tile(obs, (N // 1000, 1, 1)), np.tile(alleleid, (N // 1000, 1))
+    h = capi.HipPolyChain(obs, alleleid, allelenum, K)
+    h.setseeds(13, 4, 1972)
+    h.chain_init(np.array([np.float32(h.ran1()) for _ in range(K)], dtype=np.float32))
+else:
+    geno, an, mi = synth.make_diploid(N, L, K)
+    h = capi.HipChain(geno, an, mi, K)
+    h.setseeds(13, 4, 1972)
+    h.chain_init(np.array([h.ran1() for _ in range(K)], dtype=np.float32))
 h.iteration(); h.iteration()
 buf = np.zeros((4096, 8), dtype=np.uint64)
 h.lib.isg_diag_stamps(buf.ctypes.data_as(C.c_void_p))
 s = buf[100:min(N, 4000)].astype(np.int64)
-if os.environ.get("INSTRUCT_ZQ_COOP", "1") != "0":
+if tetra:
+    order = [0, 1, 2, 3, 4, 5]
+    names = ["top->draws+counts", "->reduced+published", "->gathered", "->attempts", "->walk"]
+    ss = s[:, order]
+    d = np.diff(ss, axis=1)
+elif os.environ.get("INSTRUCT_ZQ_COOP", "1") != "0":
     order = [0, 6, 7, 1, 2, 3, 4, 5]
     names = ["top->loads issued", "->buckets done", "->counts+store", "->published", "->gathered", "->attempts", "->walk"]
     if os.environ.get("INSTRUCT_ZQ_SPEC", "1") != "0":
