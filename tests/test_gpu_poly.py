@@ -25,7 +25,7 @@ EXTRA = {
     "x_a5k12": (50, 70, 12, 5, 0.10, 3, 1, 1, 1, 1, 1, (23, 9, 2001)),
     "x_a3k20": (30, 700, 20, 3, 0.05, 2, 1, 1, 1, 1, 1, (24, 10, 2002)),  # several workgroups per individual, K > 16
     "x_a4k3": (25, 1500, 3, 4, 0.20, 2, 1, 1, 0, 1, 1, (25, 11, 2003)),
-    "x_wide": (4, 33500, 3, 3, 0.05, 2, 1, 1, 1, 1, 1, (26, 12, 2004)),   # more loci than 128 workgroups x 256 lanes
+    "x_wide": (3, 66500, 3, 3, 0.05, 2, 1, 1, 1, 1, 1, (26, 12, 2004)),   # more loci than 128 workgroups x 512 lanes: several passes
 }
 
 
