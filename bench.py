@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-keyed", action="store_true")
     ap.add_argument("--no-tetra", action="store_true", help="skip the ploidy 4 (config 5) leg")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the several-chains-on-one-GPU leg (profiling: keeps per-kernel averages single-chain)")
     args = ap.parse_args()
 
     import torch
@@ -293,7 +294,8 @@ def main():
                              "gelman_rubin": k["gelman_rubin"],
                              "note": "counter-based stream positions: bit-identical to the oracle's keyed schedule, statistically equivalent to the reference"}
         if world == 1 and not args.no_tetra:
-            line["concurrent_chains"] = concurrent_chains_leg(geno, an, mi, K, local, max(4, args.steps // 2))
+            if not args.no_concurrent:
+                line["concurrent_chains"] = concurrent_chains_leg(geno, an, mi, K, local, max(4, args.steps // 2))
             line["ploidy4"] = tetra_leg(local, max(2, args.steps // 4), 1, not args.no_cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
