@@ -770,7 +770,22 @@ __device__ __forceinline__ int bucket_f32(float xf, const float (&F)[KMAX], cons
 {
 	float cum[KMAX];
 	const float run = prefix_f32<KMAX>(F, qf, K, cum);
-	return bucket_from_cum<KMAX>(xf, cum, run, K, amb);
+	if (KMAX > 8) return bucket_from_cum<KMAX>(xf, cum, run, K, amb);
+	/* few clusters: the per-threshold band tests schedule better than the running minimum (measured: 0.50 vs
+	 * 0.58 ms for the keyed kernel at K = 5; the other way round at K = 10) */
+	const float p = xf * run, marg = 6e-6f * run;
+	bool a = !(run > 1e-30f && run < 1e30f) || !(xf > 4e-6f && xf < 1.0f - 4e-6f);
+	int z = 0;
+#pragma unroll
+	for (int m = 0; m < KMAX - 1; m++) {
+		if (m < K - 1) {
+			const float dd = p - cum[m];
+			z += (dd > 0.f) ? 1 : 0;
+			a |= !(dd > marg || dd < -marg);
+		}
+	}
+	*amb = a;
+	return z;
 }
 
 /* Z draws of one individual; `cur` = stream state at its first position, `off` = that position counted
