@@ -65,6 +65,10 @@ struct DevView {
 	double *freq;
 	float *freqf;        /* single precision copy of freq, [L][Amax][KPF]: pre-filter of the Z draws */
 	int KPF;
+	/* log-likelihood terms as functions of (locus, alleles, cluster[, generation]) -- rebuilt when freq changes:
+	 *   lftab [L][Amax][K]                log freq                          (copies whose partner sits in another cluster)
+	 *   lltab [50][L][Amax][Amax][K]      log genofreq(generation, f0, f1)  (both copies in cluster k); null if too large */
+	double *lftab, *lltab;
 	const double *tape;  /* replay schedule: the uniforms of the ZQ phase in stream order */
 	unsigned long long tape_len;
 	int *cnt;
@@ -386,6 +390,102 @@ __device__ __forceinline__ isg_acc2 block_reduce_acc2(const isg_acc2 &a, long lo
  * To keep the wave convergent each lane takes exactly two logarithms per locus -- of
  * (genofreq(g_cur), genofreq(g_prop)) or of (f0, f1) -- and sorts the results into three
  * order-independent accumulators: current-generation terms, proposed-generation terms, common terms. */
+/*
+ * The terms log_ld_indv adds per locus (mcmc.c:1735-1770) only depend on (locus, allele pair, cluster pair,
+ * generation), and freq changes once per iteration: N x L evaluations of genofreq + log become K L Amax^2 x 50
+ * table entries (the same expressions, evaluated once: genofreq's loop over the generations is exactly the
+ * recurrence below, mcmc.c:1683-1703) and N x L lookups.  One lane per (locus, a0, a1, cluster).
+ */
+__global__ void k_lltab(DevView d)
+{
+	const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t per = (size_t)d.L * d.Amax * d.Amax * d.K;
+	if (id >= per) return;
+	const int k = (int)(id % d.K);
+	const int a1 = (int)((id / d.K) % d.Amax), a0 = (int)((id / d.K / d.Amax) % d.Amax), j = (int)(id / d.K / d.Amax / d.Amax);
+	const double f0 = d.freq[((size_t)j * d.Amax + a0) * d.KP + k], f1 = d.freq[((size_t)j * d.Amax + a1) * d.KP + k];
+	if (a1 == 0) d.lftab[((size_t)j * d.Amax + a0) * d.K + k] = isg_log(f0);
+	if (!d.lltab) return;
+	if (a0 == a1) { /* isg_genofreq(hom): result after g - 1 rounds of the loop */
+		double result = f0 * f0, temp = 2 * f0 * (1 - f0);
+		for (int g = 1; g <= 50; g++) {
+			d.lltab[(size_t)(g - 1) * per + id] = isg_log(result);
+			temp /= 2;
+			result += temp / 2;
+		}
+	} else {
+		for (int g = 1; g <= 50; g++) d.lltab[(size_t)(g - 1) * per + id] = isg_log(2 * f0 * f1 * isg_scalbn(1.0, -(g - 1)));
+	}
+}
+
+/* log_ld_indv from the tables (same values, same exact accumulation as k_loglik) */
+template <int BLOCK, bool PAIR>
+__global__ void __launch_bounds__(BLOCK) k_loglik_tab(DevView d)
+{
+	__shared__ long long sm[(BLOCK / 64) * 3];
+	const int i = blockIdx.x;
+	int gp = 1, gc;
+	if (PAIR) {
+		gp = d.genprop[i];
+		gc = d.gen[i];
+		if (gp == gc) return;
+	} else {
+		gc = (d.mode == 2) ? d.gen[i] : -1;
+	}
+	const double log2c = isg_log(2.0);
+	isg_acc2 accC, accP, accX;
+	isg_acc2_zero(&accC);
+	isg_acc2_zero(&accP);
+	isg_acc2_zero(&accX);
+	const size_t rowb = (size_t)d.Lp * 2, per = (size_t)d.L * d.Amax * d.Amax * d.K;
+	const uint8_t *grow = d.geno + (size_t)i * rowb;
+	const uint8_t *zrow = d.z + (size_t)i * rowb;
+	const double *TC = (gc >= 1) ? d.lltab + (size_t)(gc - 1) * per : d.lltab, *TP = d.lltab + (size_t)(gp - 1) * per;
+	for (int j0 = threadIdx.x * ISG_LPT; j0 < d.Lp; j0 += BLOCK * ISG_LPT) {
+		const uint2 g = *(const uint2 *)(grow + (size_t)j0 * 2);
+		const uint2 zz = *(const uint2 *)(zrow + (size_t)j0 * 2);
+		unsigned long long gb = ((unsigned long long)g.y << 32) | g.x, zb = ((unsigned long long)zz.y << 32) | zz.x;
+#pragma unroll
+		for (int l = 0; l < ISG_LPT; l++) {
+			unsigned a0 = (unsigned)(gb >> (16 * l)) & 0xff, a1 = (unsigned)(gb >> (16 * l + 8)) & 0xff;
+			unsigned z0 = (unsigned)(zb >> (16 * l)) & 0xff, z1 = (unsigned)(zb >> (16 * l + 8)) & 0xff;
+			const bool valid = (a0 != 0xff);
+			if (!valid) { a0 = a1 = 0; z0 = z1 = 0; }
+			const int j = (j0 + l < d.L) ? j0 + l : 0;
+			const bool geno_term = (gc >= 0 && z0 == z1);
+			if (geno_term) {
+				const size_t e = (((size_t)j * d.Amax + a0) * d.Amax + a1) * d.K + z0;
+				isg_acc2_add(&accC, valid ? TC[e] : 0.0);
+				if (PAIR) isg_acc2_add(&accP, valid ? TP[e] : 0.0);
+			} else {
+				const double L0 = d.lftab[((size_t)j * d.Amax + a0) * d.K + z0], L1 = d.lftab[((size_t)j * d.Amax + a1) * d.K + z1];
+				isg_acc2_add(&accX, valid ? L0 : 0.0);
+				isg_acc2_add(&accX, valid ? L1 : 0.0);
+				isg_acc2_add(&accX, (valid && a0 != a1) ? log2c : 0.0);
+			}
+		}
+	}
+	isg_acc2 rc, rp, rx;
+	rc = block_reduce_acc2<BLOCK>(accC, sm);
+	rx = block_reduce_acc2<BLOCK>(accX, sm);
+	if (PAIR) rp = block_reduce_acc2<BLOCK>(accP, sm);
+	if (threadIdx.x == 0) {
+		isg_acc2 tc = rc;
+		isg_acc2_merge(&tc, &rx);
+		double lc = isg_acc2_value(&tc);
+		if (PAIR) {
+			isg_acc2 tp = rp;
+			isg_acc2_merge(&tp, &rx);
+			double lp = isg_acc2_value(&tp);
+			double mh = isg_exp(lp - lc);
+			double thr = (1 > mh) ? mh : 1; /* MIN2(1, mhratio), mcmc.h:10 */
+			if (d.uacc[i] < thr) d.gen[i] = gp;
+		} else {
+			d.indvlkh[i] = lc;
+		}
+	}
+}
+
 template <int BLOCK, bool PAIR>
 __global__ void __launch_bounds__(BLOCK) k_loglik(DevView d)
 {
@@ -2046,6 +2146,15 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	DALLOC(d.freq, double, (size_t)Lp * Amax * KP);
 	d.KPF = (K + 3) & ~3;
 	DALLOC(d.freqf, float, (size_t)Lp * Amax * d.KPF);
+	d.lftab = d.lltab = nullptr;
+	if (cfg->type_freq == 1) { /* (-y 0 mixes the frequencies with the individual's qq: no tables) */
+		const char *e = getenv("INSTRUCT_LL_TABLES");
+		if (!(e && atoi(e) == 0)) {
+			DALLOC(d.lftab, double, (size_t)L * Amax * K);
+			const size_t ent = (size_t)50 * L * Amax * Amax * K;
+			if (cfg->mode == 2 && ent * sizeof(double) <= ((size_t)1 << 30)) { DALLOC(d.lltab, double, ent); }
+		}
+	}
 	c->d_tape = nullptr;
 	c->tape_cap = 0;
 	c->nvalid_total = 0;
@@ -2135,7 +2244,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 		return;
 	}
 	DevView &d = c->d;
-	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(d.cnt);
+	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(d.lftab); (void)hipFree(d.lltab); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
 	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S); (void)hipFree(c->d_state); (void)hipFree(c->d_ratios); (void)hipFree(c->d_total);
 	prof_collect(c);
@@ -2183,6 +2292,12 @@ static int refresh_freqf(isg_ctx *c)
 	prof_begin(c);
 	hipLaunchKernelGGL(k_freqf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d);
 	prof_end(c, "k_freqf");
+	if (d.lftab) {
+		const size_t per = (size_t)d.L * d.Amax * d.Amax * d.K;
+		prof_begin(c);
+		hipLaunchKernelGGL(k_lltab, dim3((unsigned)((per + 127) / 128)), dim3(128), 0, c->stream, d);
+		prof_end(c, "k_lltab");
+	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -2358,7 +2473,8 @@ extern "C" int isg_update_G(isg_ctx *c)
 	hipLaunchKernelGGL(k_gprop<1024>, dim3(1), dim3(1024), 0, c->stream, d, (const double *)d_S, base, is_keyed(c) ? 1 : 0, c->d_pos);
 	prof_end(c, "k_gprop");
 	prof_begin(c);
-	hipLaunchKernelGGL((k_loglik<256, true>), dim3(d.N), dim3(256), 0, c->stream, d);
+	if (d.lltab) hipLaunchKernelGGL((k_loglik_tab<256, true>), dim3(d.N), dim3(256), 0, c->stream, d);
+	else hipLaunchKernelGGL((k_loglik<256, true>), dim3(d.N), dim3(256), 0, c->stream, d);
 	prof_end(c, "k_loglik_pair");
 	HIPCHK(hipGetLastError());
 	c->h_gen = false;
@@ -2522,7 +2638,8 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 	if (c->poly) return poly_cal_lkh(c);
 	DevView &d = c->d;
 	prof_begin(c);
-	hipLaunchKernelGGL((k_loglik<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
+	if (d.lltab || (d.lftab && d.mode == 1)) hipLaunchKernelGGL((k_loglik_tab<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
+	else hipLaunchKernelGGL((k_loglik<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
 	prof_end(c, "k_loglik_lkh");
 	prof_begin(c);
 	hipLaunchKernelGGL(k_lkh_total<1024>, dim3(1), dim3(1024), 0, c->stream, d, c->d_total);
