@@ -54,6 +54,11 @@ def build_host(force=False):
     srcs = [src, os.path.join(HOST, "instruct_types.h"), os.path.join(ROOT, "include", "instruct_hip.h")]
     if force or _newer(obj, srcs):
         _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+    # the streaming reader: in place of the reference's data_interface.o (optional, independent of the sampler)
+    rsrc = os.path.join(HOST, "data_interface_stream.c")
+    robj = os.path.join(HOST, "data_interface_stream.o")
+    if force or _newer(robj, [rsrc, os.path.join(HOST, "instruct_types.h")]):
+        _run(["gcc", "-O2", "-fPIC", "-Wall", "-c", rsrc, "-o", robj])
     return obj
 
 

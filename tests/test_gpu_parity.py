@@ -302,6 +302,30 @@ def test_dropin_cli_output_equals_reference_cli_output_ploidy4(tmp_path):
     assert body(str(out)) == body(os.path.join(gu.GOLDEN, "t1_cli_output.txt"))
 
 
+def test_reader_and_sampler_replaced_cli_output_equals_reference(tmp_path):
+    """oracle/_ref/InStruct_full = the reference driver around BOTH of this repository's objects (streaming reader
+    + MI355X sampler): same result files as the pure reference binary, diploid and ploidy 4."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "InStruct_full")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/InStruct_full not built (needs the reference objects; built in the dev container)")
+
+    def body(path):
+        return [l for l in open(path, "rb").read().split(b"\n")
+                if not (l.strip().startswith((b"Data File:", b"Output File:")) or b"InStruct" in l and b"-d" in l)]
+    out = tmp_path / "d.txt"
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out), "-K", "3", "-L", "100", "-N", "50", "-p", "2",
+           "-u", "200", "-b", "100", "-t", "10", "-c", "2", "-v", "2", "-g", "1", "-r", "5", "-j", "5",
+           "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "1"]
+    log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
+    assert body(str(out)) == body(os.path.join(gu.GOLDEN, "c1_cli_output.txt"))
+    out4 = tmp_path / "t.txt"
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "t1.txt"), "-o", str(out4)] + gu.make_golden.TETRA_CLI
+    log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
+    assert body(str(out4)) == body(os.path.join(gu.GOLDEN, "t1_cli_output.txt"))
+
+
 @pytest.fixture(scope="module")
 def full_size():
     geno, an, mi = synth.make_diploid(10000, 5000, 5)
