@@ -146,6 +146,33 @@ def test_replay_zq_kernel_variants_bit_exact_vs_canonical_oracle(case, env, monk
     h.close()
 
 
+def test_checkpoint_and_resume_continue_the_same_chain():
+    """The sampler state at an iteration boundary is (z, qq, generation, selfing rates, alpha, stream position):
+    a new context restored from it through the setters continues bit-identically (the reference cannot resume)."""
+    geno, an, mi = synth.code_diploid(synth.raw_alleles(40, 300, 4, 2, 3, 0.05, 31))
+    K = 4
+    ref = capi.HipChain(geno, an, mi, K)
+    ref.setseeds(13, 4, 1972)
+    initd = np.array([ref.ran1() for _ in range(K)], dtype=np.float32)
+    ref.chain_init(initd)
+    ref.run(7)
+    a = capi.HipChain(geno, an, mi, K)
+    a.setseeds(13, 4, 1972)
+    [a.ran1() for _ in range(K)]
+    a.chain_init(initd)
+    a.run(3)
+    snap = dict(z=a.z(), qq=a.qq(), gen=a.generation(), S=a.self_rates(), alpha=a.alpha(), seeds=a.seeds())
+    a.close()
+    b = capi.HipChain(geno, an, mi, K)
+    b.set_z(snap["z"]); b.set_qq(snap["qq"]); b.set_generation(snap["gen"]); b.set_self_rates(snap["S"]); b.set_alpha(snap["alpha"])
+    b.setseeds(*snap["seeds"])
+    b.run(4)
+    for name in ("z", "qq", "qqnum", "generation", "self_rates", "freq", "indvlkh"):
+        assert np.array_equal(getattr(b, name)(), getattr(ref, name)()), name
+    assert b.alpha() == ref.alpha() and b.totallkh() == ref.totallkh() and b.seeds() == ref.seeds()
+    ref.close(); b.close()
+
+
 def _counts_hash(cnt, an):
     K, L, A = cnt.shape
     mask = np.arange(A)[None, :] < an[:, None]
