@@ -329,6 +329,23 @@ def test_dropin_cli_output_equals_reference_cli_output_ploidy4(tmp_path):
     assert body(str(out)) == body(os.path.join(gu.GOLDEN, "t1_cli_output.txt"))
 
 
+def test_dropin_k_scan_output_equals_reference(tmp_path):
+    """`-ik 1 -kv 2 3`: the driver runs every chain for K = 2 and K = 3 and keeps the K with the smallest DIC
+    (InStruct.c:536-601); the drop-in re-creates its device context when K changes."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "InStruct_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
+    out = tmp_path / "k.txt"
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out)] + gu.make_golden.KSCAN_CLI
+    log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
+
+    def body(path):
+        return [l for l in open(path, "rb").read().split(b"\n")
+                if not (l.strip().startswith((b"Data File:", b"Output File:")) or b"InStruct" in l and b"-d" in l)]
+    assert body(str(out)) == body(os.path.join(gu.GOLDEN, "c1_kscan_output.txt"))
+
+
 def test_reader_and_sampler_replaced_cli_output_equals_reference(tmp_path):
     """oracle/_ref/InStruct_full = the reference driver around BOTH of this repository's objects (streaming reader
     + MI355X sampler): same result files as the pure reference binary, diploid and ploidy 4."""
