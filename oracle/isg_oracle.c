@@ -262,6 +262,55 @@ static double log_ld_indv(const orc_chain *c, int gen, int i)
 	return sum2_val(&t);
 }
 
+/* genofreq_inbreedcoff (mcmc.c:1705-1723), diploid */
+static double genofreq_F(const orc_chain *c, int a0, int a1, double f0, double f1, double inbreed)
+{
+	if (a0 == a1) return m_pow(c, f0, (double)c->p.P) * (1 - inbreed) + f0 * inbreed;
+	return 2 * f0 * f1 * (1 - inbreed);
+}
+
+/* the terms log_ld_F_pop (mcmc.c:1776-1809) adds for individual i, handed to `add` one by one in its order */
+typedef void (*term_sink)(void *ctx, double v);
+static void F_pop_terms(const orc_chain *c, const double *inbreed, int i, term_sink add, void *ctx)
+{
+	int j;
+	for (j = 0; j < c->p.L; j++) {
+		int a0, a1, z0, z1;
+		if (!c->valid[(long)i * c->p.L + j]) continue;
+		a0 = GENO(c, i, j, 0); a1 = GENO(c, i, j, 1);
+		z0 = ZZ(c, i, j, 0); z1 = ZZ(c, i, j, 1);
+		if (z0 == z1) {
+			add(ctx, m_log(c, genofreq_F(c, a0, a1, FREQ(c, z0, j, a0), FREQ(c, z1, j, a1), inbreed[z0])));
+		} else {
+			add(ctx, m_log(c, FREQ(c, z0, j, a0)));
+			add(ctx, m_log(c, FREQ(c, z1, j, a1)));
+			if (a0 != a1) add(ctx, m_log(c, 2));
+		}
+	}
+}
+static void sink2(void *ctx, double v) { sum2_add((summer2 *)ctx, v); }
+static void sink1(void *ctx, double v) { sum_add((summer *)ctx, v); }
+static double log_ld_F_pop(const orc_chain *c, const double *inbreed, int i)
+{
+	summer2 t;
+	sum2_init(&t, c->p.accum);
+	F_pop_terms(c, inbreed, i, sink2, &t);
+	return sum2_val(&t);
+}
+/* log_ld_F_total (mcmc.c:1850-1868), mode 4.  Reference configuration: the per-individual values summed in order;
+ * canonical configuration: ONE exact sum over all terms, rounded once (what a count-based evaluation computes) */
+static double log_ld_F_total(const orc_chain *c, const double *inbreed)
+{
+	summer t;
+	int i;
+	sum_init(&t, c->p.accum);
+	for (i = 0; i < c->p.N; i++) {
+		if (c->p.accum) F_pop_terms(c, inbreed, i, sink1, &t);
+		else sum_add(&t, log_ld_F_pop(c, inbreed, i));
+	}
+	return sum_val(&t);
+}
+
 static int dt_stat(orc_chain *c, double num) /* mcmc.c:1524-1546 */
 {
 	double eps = 0.001;
@@ -402,6 +451,37 @@ void orc_update_S_POP(orc_chain *c) /* mcmc.c:913-983 */
 	free(tem_stat);
 }
 
+void orc_update_F_POP(orc_chain *c) /* update_inbreedcoff_POP, mcmc.c:986-1051 (the coefficients live in self_rates[]) */
+{
+	const orc_params *p = &c->p;
+	const int K = p->K;
+	double delta0 = 0.05, mhratio, *tmp = malloc(sizeof(double) * K);
+	int i, j, *tem_stat = malloc(sizeof(int) * K);
+	if (keyed(c)) rng_seek(c, iter_base(c) + c->ky.offS);
+	for (j = 0; j < K; j++) {
+		for (i = 0; i < K; i++) {
+			tmp[i] = c->self_rates[i];
+			if (p->back_refl == 0) tem_stat[i] = c->state[i];
+		}
+		if (p->back_refl == 1) {
+			tmp[j] = rng_next(c) * 2 * delta0 - delta0;
+			tmp[j] += c->self_rates[j];
+			if (tmp[j] <= 0.000) tmp[j] = 0.000 - tmp[j];
+			else if (tmp[j] >= 1.000) tmp[j] = 1.000 - (tmp[j] - 1.000);
+		} else {
+			tmp[j] = adpt_indp(c, &tem_stat[j], c->state[j]);
+		}
+		mhratio = log_ld_F_total(c, tmp) - log_ld_F_total(c, c->self_rates);
+		if (p->back_refl == 0) mhratio *= hastings_stat(tem_stat, c->state, K);
+		if (rng_next(c) < m_exp(c, MIN2(1, mhratio))) { /* sic: MIN2(1, .) on the log ratio (mcmc.c:1040) */
+			c->self_rates[j] = tmp[j];
+			if (p->back_refl == 0) c->state[j] = tem_stat[j];
+		}
+	}
+	free(tmp);
+	free(tem_stat);
+}
+
 void orc_update_G(orc_chain *c) /* mcmc.c:1053-1091 */
 {
 	const orc_params *p = &c->p;
@@ -477,7 +557,7 @@ void orc_cal_lkh(orc_chain *c) /* mcmc.c:1916-1942 */
 	summer t;
 	sum_init(&t, c->p.accum);
 	for (i = 0; i < c->p.N; i++) {
-		c->indvlkh[i] = log_ld_indv(c, c->p.mode == 2 ? c->generation[i] : -1, i);
+		c->indvlkh[i] = (c->p.mode == 4) ? log_ld_F_pop(c, c->self_rates, i) : log_ld_indv(c, c->p.mode == 2 ? c->generation[i] : -1, i);
 		sum_add(&t, c->indvlkh[i]);
 	}
 	c->totallkh = sum_val(&t);
@@ -490,6 +570,7 @@ void orc_iteration(orc_chain *c) /* mcmc.c:210-215 / 152-155 */
 		orc_update_S_POP(c);
 		orc_update_G(c);
 	}
+	if (c->p.mode == 4) orc_update_F_POP(c);
 	orc_update_ZQ(c, 0);
 	orc_update_alpha(c);
 	orc_cal_lkh(c);
@@ -518,6 +599,11 @@ void orc_chain_init_stage(orc_chain *c, const float *initd_row, int stage)
 				if (p->back_refl == 0) c->state[i] = dt_stat(c, c->self_rates[i]);
 			}
 		}
+		if (p->mode == 4) /* mcmc_POP_inbreedcoff, mcmc.c:255-259: no generations */
+			for (i = 0; i < p->K; i++) {
+				c->self_rates[i] = initd_row[i];
+				if (p->back_refl == 0) c->state[i] = dt_stat(c, c->self_rates[i]);
+			}
 	} else {
 		orc_update_ZQ(c, 1);
 	}
@@ -594,6 +680,11 @@ static void store_chn(orc_chain *c, orc_result *r) /* mcmc.c:1320-1456 */
 		runmean(&r->qq[i], c->qq[i], r->step);
 		runmean(&r->qq2[i], c->qq[i] * c->qq[i], r->step);
 	}
+	if (p->mode == 4)
+		for (i = 0; i < p->K; i++) {
+			runmean(&r->self_rates[i], c->self_rates[i], r->step);
+			runmean(&r->self_rates2[i], c->self_rates[i] * c->self_rates[i], r->step);
+		}
 	if (p->mode == 2) {
 		for (i = 0; i < p->K; i++) {
 			runmean(&r->self_rates[i], c->self_rates[i], r->step);

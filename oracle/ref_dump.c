@@ -65,6 +65,10 @@ static void dump_chain(CHAIN *c, SEQDATA d)
 	fprintf(G, "chain steps=%ld step=%ld flag_empty=%d totallkh=%a totallkh2=%a\n", c->steps, c->step,
 		c->flag_empty_cluster, c->totallkh, c->totallkh2);
 	dump_vec(G, "chain indvlkh", c->indvlkh, D.N);
+	if (d.mode == 4) {
+		dump_vec(G, "chain self_rates", c->inbreed, D.K);
+		dump_vec(G, "chain self_rates2", c->inbreed2, D.K);
+	}
 	if (d.mode == 2) {
 		dump_vec(G, "chain self_rates", c->self_rates, D.K);
 		dump_vec(G, "chain self_rates2", c->self_rates2, D.K);
@@ -114,6 +118,12 @@ static CHAIN run_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg, int deta
 		fprintf(G, "chain %d geninit hgen=%016llx", chn, (unsigned long long)hash_i32v(ptr->generation, D.N));
 		seeds_line();
 	}
+	if (data.mode == 4) { /* mcmc_POP_inbreedcoff, mcmc.c:255-259 */
+		for (i = 0; i < data.popnum; i++) {
+			ptr->inbreed[i] = initial.initd[chn][i];
+			if (data.back_refl == 0) ptr->state[i] = dt_stat(ptr->inbreed[i]);
+		}
+	}
 	update_ZQ(&ptr, data, 1, &qqnum);
 	flatten(ptr, data, qqnum);
 	fprintf(G, "chain %d zqinit hz=%016llx hqq=%016llx", chn, (unsigned long long)hash_z(&D, zflat),
@@ -136,6 +146,14 @@ static CHAIN run_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg, int deta
 			seeds_line();
 			update_G(data, &ptr);
 			fprintf(G, "it %ld G hgen=%016llx", step, (unsigned long long)hash_i32v(ptr->generation, D.N));
+			seeds_line();
+		}
+		if (data.mode == 4) { /* the loop body of mcmc.c:262-268; the inbreeding coefficients go on the S line */
+			update_inbreedcoff_POP(data, &ptr);
+			fprintf(G, "it %ld S", step);
+			for (i = 0; i < D.K; i++) fprintf(G, " %a", ptr->inbreed[i]);
+			if (data.back_refl == 0)
+				for (i = 0; i < D.K; i++) fprintf(G, " st%d", ptr->state[i]);
 			seeds_line();
 		}
 		update_ZQ(&ptr, data, 0, &qqnum);

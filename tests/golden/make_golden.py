@@ -26,6 +26,10 @@ CASES = {
     "c1_e0":    (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 0, 1, 5, 5, (13, 4, 1972), 2, 0, 10, False),
     "c1_y0":    (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 1, 0, 5, 5, (13, 4, 1972), 2, 0, 10, False),
     "c1_mode1": (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 1, 1, 5, 5, (13, 4, 1972), 1, 0, 10, False),
+    # mode 4 (-v 4): population inbreeding coefficients (mcmc_POP_inbreedcoff, mcmc.c:242-295)
+    "m4_c1": (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 1, 1, 5, 5, (13, 4, 1972), 4, 0, 10, False),
+    "m4_c1_e0": (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 0, 1, 5, 5, (13, 4, 1972), 4, 0, 10, False),
+    "m4_c1_miss": (50, 100, 3, 2, 0.05, 200, 100, 10, 2, 1, 1, 5, 5, (21, 5, 1980), 4, 0, 10, False),
     "c1_c2":    (50, 100, 3, 2, 0.00, 120, 60, 10, 2, 1, 1, 6, 5, (21, 7, 1999), 2, 0, 0, False),
     "c2s":      (200, 300, 5, 2, 0.01, 40, 20, 5, 1, 1, 1, 4, 4, (13, 4, 1972), 2, 0, 0, False),
     "c2s_a4":   (120, 150, 4, 4, 0.03, 40, 20, 5, 1, 1, 1, 4, 4, (15, 6, 1974), 2, 0, 0, False),
@@ -47,7 +51,7 @@ def poly_data_for(name):
 
 def data_for(name):
     N, L, K, A, miss = CASES[name][:5]
-    base = {"c1_e0": "c1", "c1_y0": "c1", "c1_mode1": "c1", "c1_c2": "c1"}.get(name, name)
+    base = {"c1_e0": "c1", "c1_y0": "c1", "c1_mode1": "c1", "c1_c2": "c1", "m4_c1": "c1", "m4_c1_e0": "c1", "m4_c1_miss": "c1_miss"}.get(name, name)
     seed = 20260101 + sorted(CASES).index(base)
     return synth.raw_alleles(N, L, K, 2, A, miss, seed)
 
