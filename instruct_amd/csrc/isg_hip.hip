@@ -93,9 +93,11 @@ struct ProfPending {
 };
 
 struct PolyCtx;
+struct InbreedCtx;
 struct isg_ctx {
 	isg_config cfg;
 	PolyCtx *poly = nullptr; /* ploidy 4 state (isg_poly_hip.inc) */
+	InbreedCtx *inb = nullptr; /* mode 4 state (isg_inbreed_hip.inc) */
 	DevView d;
 	int Amax;
 	hipStream_t stream;
@@ -405,7 +407,7 @@ __global__ void k_lltab(DevView d)
 	const int a1 = (int)((id / d.K) % d.Amax), a0 = (int)((id / d.K / d.Amax) % d.Amax), j = (int)(id / d.K / d.Amax / d.Amax);
 	const double f0 = d.freq[((size_t)j * d.Amax + a0) * d.KP + k], f1 = d.freq[((size_t)j * d.Amax + a1) * d.KP + k];
 	if (a1 == 0) d.lftab[((size_t)j * d.Amax + a0) * d.K + k] = isg_log(f0);
-	if (!d.lltab) return;
+	if (!d.lltab || d.mode != 2) return;
 	if (a0 == a1) { /* isg_genofreq(hom): result after g - 1 rounds of the loop */
 		double result = f0 * f0, temp = 2 * f0 * (1 - f0);
 		for (int g = 1; g <= 50; g++) {
@@ -430,7 +432,7 @@ __global__ void __launch_bounds__(BLOCK) k_loglik_tab(DevView d)
 		gc = d.gen[i];
 		if (gp == gc) return;
 	} else {
-		gc = (d.mode == 2) ? d.gen[i] : -1;
+		gc = (d.mode == 2) ? d.gen[i] : (d.mode == 4 ? 1 : -1); /* mode 4: one slot holding log genofreq_inbreedcoff */
 	}
 	const double log2c = isg_log(2.0);
 	isg_acc2 accC, accP, accX;
@@ -2085,6 +2087,11 @@ static int poly_update_S_POP(isg_ctx *c);
 static int poly_update_ZQ(isg_ctx *c, int init_flag);
 static int poly_cal_lkh(isg_ctx *c);
 static int poly_count_alleles(isg_ctx *c, int32_t *counts);
+extern "C" void isg_ctx_destroy(isg_ctx *c);
+static int inbreed_update_F_POP(isg_ctx *c);
+static int inbreed_cal_lkh(isg_ctx *c);
+static int inbreed_alloc(isg_ctx *c);
+static void inbreed_free(isg_ctx *c);
 #define NOT_POLY(c, what) if ((c)->poly) return fail(what ": not part of the ploidy 4 chain (poly_geno.c:98-116)")
 
 extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, const int32_t *geno, const int32_t *missindx, isg_ctx **out)
@@ -2093,7 +2100,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	if (cfg->P == 4) return fail("isg_ctx_create: ploidy 4 data goes through isg_ctx_create_poly");
 	if (cfg->P != 2) return fail("isg_ctx_create: only ploidy 2 and 4 are supported");
 	if (cfg->K < 1 || cfg->K > ISG_KCAP) return fail("isg_ctx_create: K must be in 1..32");
-	if (cfg->mode != 1 && cfg->mode != 2) return fail("isg_ctx_create: mode must be 1 or 2");
+	if (cfg->mode != 1 && cfg->mode != 2 && cfg->mode != 4) return fail("isg_ctx_create: mode must be 1, 2 or 4");
 	if (cfg->N < 1 || cfg->L < 1) return fail("isg_ctx_create: empty problem");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("isg_ctx_create: no HIP device available (the MI355X path has no CPU fallback)");
@@ -2153,6 +2160,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 			DALLOC(d.lftab, double, (size_t)L * Amax * K);
 			const size_t ent = (size_t)50 * L * Amax * Amax * K;
 			if (cfg->mode == 2 && ent * sizeof(double) <= ((size_t)1 << 30)) { DALLOC(d.lltab, double, ent); }
+			if (cfg->mode == 4) { DALLOC(d.lltab, double, ent / 50); } /* one slot: log genofreq_inbreedcoff */
 		}
 	}
 	c->d_tape = nullptr;
@@ -2226,6 +2234,10 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	c->raw_valid = true;
 	c->prof = false;
 	keyed_layout(c);
+	if (cfg->mode == 4) {
+		if (!d.lltab) { isg_ctx_destroy(c); return fail("isg_ctx_create: mode 4 needs its log-likelihood table (INSTRUCT_LL_TABLES must not be 0)"); }
+		if (inbreed_alloc(c)) { isg_ctx_destroy(c); return 1; }
+	}
 	*out = c;
 	return 0;
 }
@@ -2243,6 +2255,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 		delete c;
 		return;
 	}
+	inbreed_free(c);
 	DevView &d = c->d;
 	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(d.lftab); (void)hipFree(d.lltab); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
@@ -2439,6 +2452,10 @@ extern "C" int isg_update_P(isg_ctx *c)
 /* ---- update_S_POP ---- */
 extern "C" int isg_update_S_POP(isg_ctx *c)
 {
+	if (c->cfg.mode == 4 && !c->poly) {
+		HIPCHK(hipSetDevice(c->cfg.device));
+		return inbreed_update_F_POP(c); /* the population coefficients of mode 4 (update_inbreedcoff_POP) */
+	}
 	if (c->cfg.mode != 2) return 0;
 	HIPCHK(hipSetDevice(c->cfg.device));
 	if (c->poly) return poly_update_S_POP(c);
@@ -2636,6 +2653,7 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
 	if (c->poly) return poly_cal_lkh(c);
+	if (c->cfg.mode == 4) return inbreed_cal_lkh(c);
 	DevView &d = c->d;
 	prof_begin(c);
 	if (d.lltab || (d.lftab && d.mode == 1)) hipLaunchKernelGGL((k_loglik_tab<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
@@ -2650,6 +2668,7 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 }
 
 #include "isg_poly_hip.inc"
+#include "isg_inbreed_hip.inc"
 
 extern "C" int isg_iteration(isg_ctx *c)
 {
@@ -2662,6 +2681,7 @@ extern "C" int isg_iteration(isg_ctx *c)
 		if (isg_update_S_POP(c)) return 1;
 		if (isg_update_G(c)) return 1;
 	}
+	if (c->cfg.mode == 4 && isg_update_S_POP(c)) return 1;
 	if (isg_update_ZQ(c, 0)) return 1;
 	if (isg_update_alpha(c)) return 1;
 	if (isg_cal_lkh(c)) return 1;
@@ -2710,6 +2730,20 @@ extern "C" int isg_chain_init(isg_ctx *c, const float *initd)
 		HIPCHK(hipMemcpyAsync(c->d_state, c->state.data(), sizeof(int) * K, hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
 		c->h_gen = c->h_S = true;
+	}
+	if (c->cfg.mode == 4) { /* mcmc_POP_inbreedcoff, mcmc.c:255-259: coefficients and their states, no generations */
+		for (int k = 0; k < K; k++) {
+			c->S[k] = (double)initd[k];
+			if (c->cfg.back_refl == 0) {
+				int st = isg_dt_stat(c->S[k]);
+				if (st < 0) return fail("The value of selfing rate or inbreeding coefficient is beyond [0,1]!");
+				c->state[k] = st;
+			}
+		}
+		HIPCHK(hipMemcpyAsync(c->d_S, c->S.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(c->d_state, c->state.data(), sizeof(int) * K, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		c->h_S = true;
 	}
 	return isg_update_ZQ(c, 1);
 }

@@ -65,7 +65,7 @@ def load():
         lib.orc_gelman_rubin.restype = C.c_double
         lib.orc_gelman_rubin.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.orc_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        for f in ("orc_destroy", "orc_update_P", "orc_update_S_POP", "orc_update_G", "orc_update_alpha", "orc_cal_lkh",
+        for f in ("orc_destroy", "orc_update_P", "orc_update_S_POP", "orc_update_F_POP", "orc_update_G", "orc_update_alpha", "orc_cal_lkh",
                   "orc_iteration"):
             getattr(lib, f).argtypes = [C.c_void_p]
         lib.orc_update_ZQ.argtypes = [C.c_void_p, C.c_int]
@@ -126,7 +126,8 @@ class OrcChain:
         self.lib.orc_chain_init(self.h, _ptr(v))
 
     def update_P(self): self.lib.orc_update_P(self.h)
-    def update_S_POP(self): self.lib.orc_update_S_POP(self.h)
+    def update_S_POP(self):
+        (self.lib.orc_update_F_POP if self.mode == 4 else self.lib.orc_update_S_POP)(self.h)
     def update_G(self): self.lib.orc_update_G(self.h)
     def update_ZQ(self, init_flag=0): self.lib.orc_update_ZQ(self.h, init_flag)
     def update_alpha(self): self.lib.orc_update_alpha(self.h)

@@ -54,6 +54,9 @@ SWEEP_CASES = [
     (64, 200, 4, 0.03, 4, 2, 0, 0),      # -y 0, -e 0, four alleles
     (16, 9000, 9, 0.01, 2, 2, 1, 1),     # K > 8 kernel variant, several passes per row
     (5, 8, 2, 0.3, 2, 2, 1, 1),          # tiny, individuals with (almost) everything missing
+    (50, 100, 3, 0.0, 2, 4, 1, 1),       # mode 4: population inbreeding coefficients
+    (64, 700, 4, 0.05, 3, 4, 1, 0),      # mode 4, -e 0, three alleles, several workgroups
+    (20, 60, 9, 0.02, 2, 4, 1, 1),       # mode 4, K > 8
 ]
 
 
@@ -78,6 +81,9 @@ def test_every_sweep_bit_exact_vs_canonical_oracle(case, sched):
             _same(h, o, ["self_rates", "state"] + pos, (it, "S"))
             h.update_G(); o.update_G()
             _same(h, o, ["generation"] + pos, (it, "G"))
+        if mode == 4:
+            h.update_S_POP(); o.update_S_POP()   # the inbreeding coefficients travel in the selfing-rate slots
+            _same(h, o, ["self_rates", "state"] + pos, (it, "F"))
         h.update_ZQ(0); o.update_ZQ(0)
         _same(h, o, ["z", "qq", "qqnum"] + pos, (it, "ZQ"))
         h.update_alpha(); o.update_alpha()
