@@ -394,7 +394,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	const int N = data.totalsize, K = data.popnum, L = data.locinum, A = data.allelenum_max;
 	double *qqflat = (double *)malloc(sizeof(double) * (size_t)N * K);
 	double *freqflat = data.print_freq == 1 ? (double *)malloc(sizeof(double) * (size_t)K * L * A) : NULL;
-	const int tetra = (data.ploid == 4);
+	const int tetra = (data.ploid == 4), inbr = (data.ploid == 2 && data.mode == 4);
 	int i, j, k;
 
 	memset(&mchain, 0, sizeof(mchain));
@@ -411,6 +411,10 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	if (data.mode == 2 || tetra) {
 		node.self_rates = dvector(0, K - 1);
 		node.generation = ivector(0, N - 1);
+		node.state = ivector(0, K - 1);
+	}
+	if (inbr) { /* mode 4: UPMCMC.inbreed (allocate_node, mcmc.c:524-530) */
+		node.inbreed = dvector(0, K - 1);
 		node.state = ivector(0, K - 1);
 	}
 	if (data.print_freq == 1) node.freq = d3tensor(0, K - 1, 0, L - 1, 0, A - 1);
@@ -431,6 +435,10 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 				for (k = 0; k < K; k++) node.qq[i][k] = qqflat[(size_t)i * K + k];
 			if (data.mode == 2 || tetra) {
 				isg_get_self_rates(ctx, node.self_rates);
+				isg_get_state(ctx, node.state);
+			}
+			if (inbr) {
+				isg_get_self_rates(ctx, node.inbreed);
 				isg_get_state(ctx, node.state);
 			}
 		}
@@ -466,6 +474,10 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 
 	free_dmatrix(node.qq, 0, N - 1, 0, K - 1);
 	free_dvector(node.indvlkh, 0, N - 1);
+	if (inbr) {
+		free_dvector(node.inbreed, 0, K - 1);
+		free_ivector(node.state, 0, K - 1);
+	}
 	if (data.mode == 2 || tetra) {
 		free_dvector(node.self_rates, 0, K - 1);
 		free_ivector(node.generation, 0, N - 1);
@@ -481,9 +493,9 @@ CHAIN mcmc_updating(SEQDATA data, INIT initial, int chn, CONVG *cvg) /* mcmc.c:6
 {
 	CHAIN chain;
 	memset(&chain, 0, sizeof(chain));
-	if (data.ploid == 2 && (data.mode == 1 || data.mode == 2)) return mcmc_hip_chain(data, initial, chn, cvg);
+	if (data.ploid == 2 && (data.mode == 1 || data.mode == 2 || data.mode == 4)) return mcmc_hip_chain(data, initial, chn, cvg);
 	if (data.ploid == 4 && data.autopoly == 1) return mcmc_hip_chain(data, initial, chn, cvg);
 	if (data.ploid == 4 && mcmc_POP_tetra_selfing) return mcmc_POP_tetra_selfing(data, initial, chn, cvg); /* -ap 0: reference code */
-	nrerror("this build of the sampler accelerates diploid modes 1 and 2 (-v 1, -v 2) and autotetraploids (-p 4 -ap 1); other modes need the reference mcmc.c");
+	nrerror("this build of the sampler accelerates diploid modes 1, 2 and 4 (-v 1, -v 2, -v 4) and autotetraploids (-p 4 -ap 1); other modes need the reference mcmc.c");
 	return chain;
 }

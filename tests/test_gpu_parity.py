@@ -240,6 +240,12 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
                 h.update_G()
                 f = gu.fields(next(it))
                 assert orc.fnv_i32(h.generation()) == f["hgen"] and f["seeds"] == h.seeds(), (step, "G")
+            if c["mode"] == 4:
+                h.update_S_POP()   # update_inbreedcoff_POP: the coefficients are dumped on the S line
+                line = next(it)
+                assert close(h.self_rates(), gu.floats(line)[:K]) and gu.fields(line)["seeds"] == h.seeds(), (step, "F")
+                if c["e"] == 0:
+                    assert ["st%d" % s for s in h.state()] == [t for t in line.split() if t.startswith("st")]
             h.update_ZQ(0)
             f = gu.fields(next(it))
             assert orc.fnv_i32(h.z()) == f["hz"] and orc.fnv_f64(h.qqnum()) == f["hqqnum"] and f["seeds"] == h.seeds(), (step, "ZQ")
@@ -264,8 +270,9 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
                 res["totallkh"] = float(_runmean(np.float64(res["totallkh"]), h.totallkh(), s))
                 res["qq"] = _runmean(res["qq"], h.qq(), s)
                 res["indv"] = _runmean(res["indv"], h.indvlkh(), s)
-                if c["mode"] == 2:
+                if c["mode"] in (2, 4):
                     res["S"] = _runmean(res["S"], h.self_rates(), s)
+                if c["mode"] == 2:
                     res["gen"] = _runmean(res["gen"], h.generation().astype(float), s)
                 res["n"] += 1
                 if cnt_step < c["r"]:
@@ -277,6 +284,9 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
         f = gu.fields(next(it))
         assert int(f["step"]) == res["n"] and close(res["totallkh"], float.fromhex(f["totallkh"]), 1e-6)
         assert close(res["indv"], gu.floats(next(it)), 1e-6)
+        if c["mode"] == 4:
+            assert close(res["S"], gu.floats(next(it)), 1e-6)
+            next(it)
         if c["mode"] == 2:
             assert close(res["S"], gu.floats(next(it)), 1e-6)
             next(it)
@@ -333,6 +343,22 @@ def test_dropin_cli_output_equals_reference_cli_output_ploidy4(tmp_path):
         return [l for l in open(path, "rb").read().split(b"\n")
                 if not (l.strip().startswith((b"Data File:", b"Output File:")) or b"InStruct" in l and b"-d" in l)]
     assert body(str(out)) == body(os.path.join(gu.GOLDEN, "t1_cli_output.txt"))
+
+
+def test_dropin_cli_output_equals_reference_cli_output_mode4(tmp_path):
+    """`-v 4 -e 0` (population inbreeding coefficients, adaptive independence proposals) through the drop-in"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "InStruct_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
+    out = tmp_path / "m4.txt"
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out)] + gu.make_golden.MODE4_CLI
+    log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
+
+    def body(path):
+        return [l for l in open(path, "rb").read().split(b"\n")
+                if not (l.strip().startswith((b"Data File:", b"Output File:")) or b"InStruct" in l and b"-d" in l)]
+    assert body(str(out)) == body(os.path.join(gu.GOLDEN, "c1_mode4_cli_output.txt"))
 
 
 def test_dropin_k_scan_output_equals_reference(tmp_path):
