@@ -384,7 +384,7 @@ static void keyed_layout(orc_chain *c)
 	k->offG = k->offS + 4 * K;
 	k->offZ = k->offG + 2 * N;
 	k->offA = k->offZ + N * k->SZ;
-	k->BLK = k->offA + 4;
+	k->BLK = k->offA + 4 + (c->p.mode == 3 ? 2 * N : 0); /* mode 3: update_S_IND of individual i at offA + 4 + 2 i */
 }
 void orc_keyed_get_layout(const orc_chain *c, orc_keyed_layout *out) { *out = c->ky; }
 static uint64_t iter_base(const orc_chain *c) { return c->ky.B0 + (uint64_t)c->iter * c->ky.BLK; }
@@ -482,6 +482,25 @@ void orc_update_F_POP(orc_chain *c) /* update_inbreedcoff_POP, mcmc.c:986-1051 (
 	free(tem_stat);
 }
 
+/* dgeom (mcmc.c:1596-1604) */
+static double dgeom(const orc_chain *c, double self, int gen) { return m_pow(c, self, (double)(gen - 1)) * (1 - self); }
+
+void orc_update_S_IND(orc_chain *c) /* mcmc.c:864-884 (mode 3, uniform prior) */
+{
+	const orc_params *p = &c->p;
+	double tmp, delta0 = 0.05, mhratio;
+	int j;
+	for (j = 0; j < p->N; j++) {
+		if (keyed(c)) rng_seek(c, iter_base(c) + c->ky.offA + 4 + 2 * (uint64_t)j);
+		tmp = rng_next(c) * 2 * delta0 - delta0;
+		tmp += c->self_rates[j];
+		if (tmp <= 0.0) tmp = 0.0 - tmp;
+		if (tmp >= 1.0) tmp = 1.0 - (tmp - 1);
+		mhratio = m_exp(c, m_log(c, dgeom(c, tmp, c->generation[j])) - m_log(c, dgeom(c, c->self_rates[j], c->generation[j])));
+		c->self_rates[j] = (rng_next(c) < MIN2(1, mhratio)) ? tmp : c->self_rates[j];
+	}
+}
+
 void orc_update_G(orc_chain *c) /* mcmc.c:1053-1091 */
 {
 	const orc_params *p = &c->p;
@@ -489,7 +508,8 @@ void orc_update_G(orc_chain *c) /* mcmc.c:1053-1091 */
 	double selfing, mhratio;
 	for (i = 0; i < p->N; i++) {
 		selfing = 0;
-		for (j = 0; j < p->K; j++) selfing += c->qq[(long)i * p->K + j] * c->self_rates[j];
+		if (p->mode == 3) selfing = c->self_rates[i]; /* mcmc.c:1069-1070 */
+		else for (j = 0; j < p->K; j++) selfing += c->qq[(long)i * p->K + j] * c->self_rates[j];
 		if (keyed(c)) rng_seek(c, iter_base(c) + c->ky.offG + 2 * (uint64_t)i);
 		stat = dt_stat(c, selfing);
 		if (stat == 1) {
@@ -557,7 +577,8 @@ void orc_cal_lkh(orc_chain *c) /* mcmc.c:1916-1942 */
 	summer t;
 	sum_init(&t, c->p.accum);
 	for (i = 0; i < c->p.N; i++) {
-		c->indvlkh[i] = (c->p.mode == 4) ? log_ld_F_pop(c, c->self_rates, i) : log_ld_indv(c, c->p.mode == 2 ? c->generation[i] : -1, i);
+		c->indvlkh[i] = (c->p.mode == 4) ? log_ld_F_pop(c, c->self_rates, i)
+						 : log_ld_indv(c, (c->p.mode == 2 || c->p.mode == 3) ? c->generation[i] : -1, i);
 		sum_add(&t, c->indvlkh[i]);
 	}
 	c->totallkh = sum_val(&t);
@@ -571,6 +592,10 @@ void orc_iteration(orc_chain *c) /* mcmc.c:210-215 / 152-155 */
 		orc_update_G(c);
 	}
 	if (c->p.mode == 4) orc_update_F_POP(c);
+	if (c->p.mode == 3) {
+		orc_update_S_IND(c);
+		orc_update_G(c);
+	}
 	orc_update_ZQ(c, 0);
 	orc_update_alpha(c);
 	orc_cal_lkh(c);
@@ -597,6 +622,18 @@ void orc_chain_init_stage(orc_chain *c, const float *initd_row, int stage)
 			for (i = 0; i < p->K; i++) {
 				c->self_rates[i] = initd_row[i];
 				if (p->back_refl == 0) c->state[i] = dt_stat(c, c->self_rates[i]);
+			}
+		}
+		if (p->mode == 3) { /* mcmc_INDV_selfing, mcmc.c:324-331; sic: the generations are not clamped to 50 here */
+			if (keyed(c)) {
+				for (i = 0; i < p->N; i++) {
+					rng_seek(c, 1 + 2 * (uint64_t)i);
+					c->self_rates[i] = rng_next(c);
+					c->generation[i] = rgeom(c, 1 - c->self_rates[i]);
+				}
+			} else {
+				for (i = 0; i < p->N; i++) c->self_rates[i] = rng_next(c);
+				for (i = 0; i < p->N; i++) c->generation[i] = rgeom(c, 1 - c->self_rates[i]);
 			}
 		}
 		if (p->mode == 4) /* mcmc_POP_inbreedcoff, mcmc.c:255-259: no generations */
@@ -636,7 +673,7 @@ orc_chain *orc_create(const orc_params *p, const int *allelenum, const int *geno
 	c->freq = calloc((size_t)p->K * p->L * p->Amax, sizeof(double));
 	c->qq = calloc((size_t)p->N * p->K, sizeof(double));
 	c->qqnum = calloc((size_t)p->N * p->K, sizeof(double));
-	c->self_rates = calloc(p->K, sizeof(double));
+	c->self_rates = calloc(p->K > p->N ? p->K : p->N, sizeof(double)); /* [K]; mode 3: one per individual */
 	c->indvlkh = calloc(p->N, sizeof(double));
 	c->rng.s1 = 13; c->rng.s2 = 4; c->rng.s3 = 1972; /* random.c:10-12 */
 	keyed_layout(c);
@@ -679,6 +716,14 @@ static void store_chn(orc_chain *c, orc_result *r) /* mcmc.c:1320-1456 */
 	for (i = 0; i < (long)p->N * p->K; i++) {
 		runmean(&r->qq[i], c->qq[i], r->step);
 		runmean(&r->qq2[i], c->qq[i] * c->qq[i], r->step);
+	}
+	if (p->mode == 3) {
+		for (i = 0; i < p->N; i++) {
+			runmean(&r->self_rates[i], c->self_rates[i], r->step);
+			runmean(&r->self_rates2[i], c->self_rates[i] * c->self_rates[i], r->step);
+			runmean(&r->gen[i], c->generation[i], r->step);
+			runmean(&r->gen2[i], c->generation[i] * c->generation[i], r->step);
+		}
 	}
 	if (p->mode == 4)
 		for (i = 0; i < p->K; i++) {
@@ -724,7 +769,7 @@ static void allocate_chn(orc_chain *c, orc_result *r) /* mcmc.c:588-642, 644-738
 	r->indvlkh = ones(p->N);
 	r->qq = ones((long)p->N * p->K);
 	r->qq2 = ones((long)p->N * p->K);
-	r->self_rates = ones(p->K); r->self_rates2 = ones(p->K);
+	r->self_rates = ones(p->K > p->N ? p->K : p->N); r->self_rates2 = ones(p->K > p->N ? p->K : p->N);
 	r->gen = ones(p->N); r->gen2 = ones(p->N);
 	r->freq = ones((long)p->K * p->L * p->Amax); r->freq2 = ones((long)p->K * p->L * p->Amax);
 }

@@ -65,6 +65,12 @@ static void dump_chain(CHAIN *c, SEQDATA d)
 	fprintf(G, "chain steps=%ld step=%ld flag_empty=%d totallkh=%a totallkh2=%a\n", c->steps, c->step,
 		c->flag_empty_cluster, c->totallkh, c->totallkh2);
 	dump_vec(G, "chain indvlkh", c->indvlkh, D.N);
+	if (d.mode == 3) {
+		dump_vec(G, "chain self_rates", c->self_rates, D.N);
+		dump_vec(G, "chain self_rates2", c->self_rates2, D.N);
+		dump_vec(G, "chain gen", c->gen, D.N);
+		dump_vec(G, "chain gen2", c->gen2, D.N);
+	}
 	if (d.mode == 4) {
 		dump_vec(G, "chain self_rates", c->inbreed, D.K);
 		dump_vec(G, "chain self_rates2", c->inbreed2, D.K);
@@ -118,6 +124,13 @@ static CHAIN run_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg, int deta
 		fprintf(G, "chain %d geninit hgen=%016llx", chn, (unsigned long long)hash_i32v(ptr->generation, D.N));
 		seeds_line();
 	}
+	if (data.mode == 3) { /* mcmc_INDV_selfing, mcmc.c:324-331 (prior_flag 0); sic: no clamp of the generations here */
+		for (i = 0; i < data.totalsize; i++) ptr->self_rates[i] = ran1();
+		for (i = 0; i < data.totalsize; i++) ptr->generation[i] = rgeom(1 - ptr->self_rates[i]);
+		fprintf(G, "chain %d geninit hgen=%016llx hS=%016llx", chn, (unsigned long long)hash_i32v(ptr->generation, D.N),
+			(unsigned long long)hash_f64v(ptr->self_rates, D.N));
+		seeds_line();
+	}
 	if (data.mode == 4) { /* mcmc_POP_inbreedcoff, mcmc.c:255-259 */
 		for (i = 0; i < data.popnum; i++) {
 			ptr->inbreed[i] = initial.initd[chn][i];
@@ -143,6 +156,16 @@ static CHAIN run_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg, int deta
 			for (i = 0; i < D.K; i++) fprintf(G, " %a", ptr->self_rates[i]);
 			if (data.back_refl == 0)
 				for (i = 0; i < D.K; i++) fprintf(G, " st%d", ptr->state[i]);
+			seeds_line();
+			update_G(data, &ptr);
+			fprintf(G, "it %ld G hgen=%016llx", step, (unsigned long long)hash_i32v(ptr->generation, D.N));
+			seeds_line();
+		}
+		if (data.mode == 3) { /* the loop body of mcmc.c:344-348 */
+			update_S_IND(data.totalsize, &ptr);
+			fprintf(G, "it %ld SI", step);
+			for (i = 0; i < 4 && i < D.N; i++) fprintf(G, " %a", ptr->self_rates[i]);
+			fprintf(G, " hS=%016llx", (unsigned long long)hash_f64v(ptr->self_rates, D.N));
 			seeds_line();
 			update_G(data, &ptr);
 			fprintf(G, "it %ld G hgen=%016llx", step, (unsigned long long)hash_i32v(ptr->generation, D.N));
