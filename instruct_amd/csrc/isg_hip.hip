@@ -313,7 +313,8 @@ __global__ void __launch_bounds__(BLOCK) k_gprop(DevView d, const double *S, isg
 {
 	__shared__ unsigned sm[BLOCK / 64 + 1];
 	__shared__ double Ssh[ISG_KCAP];
-	if (threadIdx.x < (unsigned)d.K) Ssh[threadIdx.x] = S[threadIdx.x];
+	const bool indiv = (d.mode == 3); /* mode 3: S has one selfing rate per individual (mcmc.c:1069-1070) */
+	if (!indiv && threadIdx.x < (unsigned)d.K) Ssh[threadIdx.x] = S[threadIdx.x];
 	__syncthreads();
 	unsigned running = 0;
 	for (int i0 = 0; i0 < d.N; i0 += BLOCK) {
@@ -321,7 +322,8 @@ __global__ void __launch_bounds__(BLOCK) k_gprop(DevView d, const double *S, isg
 		double selfing = 0;
 		int stat = 0;
 		if (i < d.N) {
-			for (int k = 0; k < d.K; k++) selfing += d.qq[(size_t)i * d.K + k] * Ssh[k];
+			if (indiv) selfing = S[i];
+			else for (int k = 0; k < d.K; k++) selfing += d.qq[(size_t)i * d.K + k] * Ssh[k];
 			stat = isg_dt_stat(selfing);
 			if (stat < 0) { atomicOr(d.err, 2u); stat = 1; }
 		}
@@ -500,7 +502,7 @@ __global__ void __launch_bounds__(BLOCK) k_loglik(DevView d)
 		gc = d.gen[i];
 		if (gp == gc) return; /* identical sums: ratio is exactly 1, accepted, generation unchanged */
 	} else {
-		gc = (d.mode == 2) ? d.gen[i] : -1;
+		gc = (d.mode == 2 || d.mode == 3) ? d.gen[i] : -1;
 	}
 	const bool expect = (gc >= 0 && d.type_freq == 0); /* -y 0: expected frequencies under qq */
 	if (expect) {
@@ -2061,6 +2063,7 @@ static void keyed_layout(isg_ctx *c)
 	uint64_t N = c->cfg.N, L = c->cfg.L, P = c->cfg.P, K = c->cfg.K, A = c->Amax;
 	uint64_t SP = 16 * A + 16, SZ = P * L + 16 * K + 16, ZI0 = 1 + 2 * N, B0 = ZI0 + N * SZ;
 	uint64_t offS = K * L * SP, offG = offS + 4 * K, offZ = offG + 2 * N, offA = offZ + N * SZ, BLK = offA + 4;
+	if (c->cfg.mode == 3) BLK += 2 * N; /* update_S_IND of individual i at offA + 4 + 2 i */
 	uint64_t v[9] = {SP, SZ, ZI0, B0, offS, offG, offZ, offA, BLK};
 	memcpy(c->ky, v, sizeof(v));
 }
@@ -2088,6 +2091,7 @@ static int poly_update_ZQ(isg_ctx *c, int init_flag);
 static int poly_cal_lkh(isg_ctx *c);
 static int poly_count_alleles(isg_ctx *c, int32_t *counts);
 extern "C" void isg_ctx_destroy(isg_ctx *c);
+static int indiv_update_S_IND(isg_ctx *c);
 static int inbreed_update_F_POP(isg_ctx *c);
 static int inbreed_cal_lkh(isg_ctx *c);
 static int inbreed_alloc(isg_ctx *c);
@@ -2100,7 +2104,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	if (cfg->P == 4) return fail("isg_ctx_create: ploidy 4 data goes through isg_ctx_create_poly");
 	if (cfg->P != 2) return fail("isg_ctx_create: only ploidy 2 and 4 are supported");
 	if (cfg->K < 1 || cfg->K > ISG_KCAP) return fail("isg_ctx_create: K must be in 1..32");
-	if (cfg->mode != 1 && cfg->mode != 2 && cfg->mode != 4) return fail("isg_ctx_create: mode must be 1, 2 or 4");
+	if (cfg->mode < 1 || cfg->mode > 4) return fail("isg_ctx_create: mode must be 1, 2, 3 or 4");
 	if (cfg->N < 1 || cfg->L < 1) return fail("isg_ctx_create: empty problem");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("isg_ctx_create: no HIP device available (the MI355X path has no CPU fallback)");
@@ -2159,7 +2163,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 		if (!(e && atoi(e) == 0)) {
 			DALLOC(d.lftab, double, (size_t)L * Amax * K);
 			const size_t ent = (size_t)50 * L * Amax * Amax * K;
-			if (cfg->mode == 2 && ent * sizeof(double) <= ((size_t)1 << 30)) { DALLOC(d.lltab, double, ent); }
+			if (cfg->mode == 2 && ent * sizeof(double) <= ((size_t)1 << 30)) { DALLOC(d.lltab, double, ent); } /* (mode 3: unclamped initial generations) */
 			if (cfg->mode == 4) { DALLOC(d.lltab, double, ent / 50); } /* one slot: log genofreq_inbreedcoff */
 		}
 	}
@@ -2208,7 +2212,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	d.tab = dt;
 	DALLOC(c->d_pos, uint64_t, 4);
 	DALLOC(c->d_err, unsigned, 1);
-	DALLOC(c->d_S, double, ISG_KCAP);
+	DALLOC(c->d_S, double, (cfg->mode == 3 && N > ISG_KCAP) ? N : ISG_KCAP); /* mode 3: one rate per individual */
 	DALLOC(c->d_state, int, ISG_KCAP);
 	DALLOC(c->d_ratios, double, (size_t)N * K);
 	DALLOC(c->d_total, double, 1);
@@ -2221,7 +2225,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	c->qq.assign((size_t)N * K, 0.0);
 	c->qqnum.assign((size_t)N * K, 0);
 	c->gen.assign(N, 0);
-	c->S.assign(K, 0.0);
+	c->S.assign(cfg->mode == 3 ? N : K, 0.0); /* mode 3: one selfing rate per individual */
 	c->state.assign(K, 0);
 	c->indvlkh.assign(N, 0.0);
 	c->cnt_h.assign((size_t)L * Amax * K, 0);
@@ -2345,7 +2349,7 @@ static int ensure_gen(isg_ctx *c)
 static int ensure_S(isg_ctx *c)
 {
 	if (c->h_S) return 0;
-	HIPCHK(hipMemcpyAsync(c->S.data(), c->d_S, sizeof(double) * c->cfg.K, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(c->S.data(), c->d_S, sizeof(double) * c->S.size(), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(c->state.data(), c->d_state, sizeof(int) * c->cfg.K, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	c->h_S = true;
@@ -2481,7 +2485,7 @@ extern "C" int isg_update_S_POP(isg_ctx *c)
 extern "C" int isg_update_G(isg_ctx *c)
 {
 	NOT_POLY(c, "isg_update_G");
-	if (c->cfg.mode != 2) return 0;
+	if (c->cfg.mode != 2 && c->cfg.mode != 3) return 0;
 	HIPCHK(hipSetDevice(c->cfg.device));
 	DevView &d = c->d;
 	double *d_S = c->d_S;
@@ -2670,6 +2674,13 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 #include "isg_poly_hip.inc"
 #include "isg_inbreed_hip.inc"
 
+extern "C" int isg_update_S_IND(isg_ctx *c) /* mode 3: update_S_IND, mcmc.c:864-884 */
+{
+	if (c->poly || c->cfg.mode != 3) return fail("isg_update_S_IND: mode 3 (-v 3) only");
+	HIPCHK(hipSetDevice(c->cfg.device));
+	return indiv_update_S_IND(c);
+}
+
 extern "C" int isg_iteration(isg_ctx *c)
 {
 	if (c->poly) {
@@ -2682,6 +2693,10 @@ extern "C" int isg_iteration(isg_ctx *c)
 		if (isg_update_G(c)) return 1;
 	}
 	if (c->cfg.mode == 4 && isg_update_S_POP(c)) return 1;
+	if (c->cfg.mode == 3) {
+		if (isg_update_S_IND(c)) return 1;
+		if (isg_update_G(c)) return 1;
+	}
 	if (isg_update_ZQ(c, 0)) return 1;
 	if (isg_update_alpha(c)) return 1;
 	if (isg_cal_lkh(c)) return 1;
@@ -2728,6 +2743,22 @@ extern "C" int isg_chain_init(isg_ctx *c, const float *initd)
 		HIPCHK(hipMemcpyAsync(c->d.gen, c->gen.data(), sizeof(int) * N, hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipMemcpyAsync(c->d_S, c->S.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipMemcpyAsync(c->d_state, c->state.data(), sizeof(int) * K, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		c->h_gen = c->h_S = true;
+	}
+	if (c->cfg.mode == 3) { /* mcmc_INDV_selfing, mcmc.c:324-331 (prior_flag 0); sic: the generations are not clamped here */
+		if (is_keyed(c)) {
+			for (int i = 0; i < N; i++) {
+				host_seek(c, 1 + 2 * (uint64_t)i);
+				c->S[i] = host_next(c);
+				c->gen[i] = isg_rgeom_u(host_next(c), 1 - c->S[i]);
+			}
+		} else {
+			for (int i = 0; i < N; i++) c->S[i] = host_next(c);
+			for (int i = 0; i < N; i++) c->gen[i] = isg_rgeom_u(host_next(c), 1 - c->S[i]);
+		}
+		HIPCHK(hipMemcpyAsync(c->d.gen, c->gen.data(), sizeof(int) * N, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(c->d_S, c->S.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
 		c->h_gen = c->h_S = true;
 	}
@@ -2849,7 +2880,7 @@ extern "C" int isg_set_self_rates(isg_ctx *c, const double *s)
 	HIPCHK(hipSetDevice(c->cfg.device));
 	if (ensure_S(c)) return 1;
 	memcpy(c->S.data(), s, sizeof(double) * c->S.size());
-	HIPCHK(hipMemcpy(c->d_S, c->S.data(), sizeof(double) * c->cfg.K, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(c->d_S, c->S.data(), sizeof(double) * c->S.size(), hipMemcpyHostToDevice));
 	return 0;
 }
 extern "C" int isg_get_state(isg_ctx *c, int32_t *s)

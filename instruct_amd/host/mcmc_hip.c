@@ -394,7 +394,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	const int N = data.totalsize, K = data.popnum, L = data.locinum, A = data.allelenum_max;
 	double *qqflat = (double *)malloc(sizeof(double) * (size_t)N * K);
 	double *freqflat = data.print_freq == 1 ? (double *)malloc(sizeof(double) * (size_t)K * L * A) : NULL;
-	const int tetra = (data.ploid == 4), inbr = (data.ploid == 2 && data.mode == 4);
+	const int tetra = (data.ploid == 4), inbr = (data.ploid == 2 && data.mode == 4), indv = (data.ploid == 2 && data.mode == 3);
 	int i, j, k;
 
 	memset(&mchain, 0, sizeof(mchain));
@@ -412,6 +412,10 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 		node.self_rates = dvector(0, K - 1);
 		node.generation = ivector(0, N - 1);
 		node.state = ivector(0, K - 1);
+	}
+	if (indv) { /* mode 3: one selfing rate and one generation per individual (allocate_node, mcmc.c:515-520) */
+		node.self_rates = dvector(0, N - 1);
+		node.generation = ivector(0, N - 1);
 	}
 	if (inbr) { /* mode 4: UPMCMC.inbreed (allocate_node, mcmc.c:524-530) */
 		node.inbreed = dvector(0, K - 1);
@@ -441,12 +445,13 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 				isg_get_self_rates(ctx, node.inbreed);
 				isg_get_state(ctx, node.state);
 			}
+			if (indv) isg_get_self_rates(ctx, node.self_rates);
 		}
 		if (data.print_iter == 1) print_info(&node, data, step, initial.update);
 		if (step == initial.burnin - 1) allocate_chn(&mchain, data);
 		if (stored) {
 			isg_get_indvlkh(ctx, node.indvlkh);
-			if (data.mode == 2 && !tetra) isg_get_generation(ctx, node.generation);
+			if ((data.mode == 2 || data.mode == 3) && !tetra) isg_get_generation(ctx, node.generation);
 			if (data.print_freq == 1) {
 				if (isg_get_freq(ctx, freqflat)) hip_fail("isg_get_freq");
 				for (k = 0; k < K; k++)
@@ -474,6 +479,10 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 
 	free_dmatrix(node.qq, 0, N - 1, 0, K - 1);
 	free_dvector(node.indvlkh, 0, N - 1);
+	if (indv) {
+		free_dvector(node.self_rates, 0, N - 1);
+		free_ivector(node.generation, 0, N - 1);
+	}
 	if (inbr) {
 		free_dvector(node.inbreed, 0, K - 1);
 		free_ivector(node.state, 0, K - 1);
@@ -493,9 +502,10 @@ CHAIN mcmc_updating(SEQDATA data, INIT initial, int chn, CONVG *cvg) /* mcmc.c:6
 {
 	CHAIN chain;
 	memset(&chain, 0, sizeof(chain));
-	if (data.ploid == 2 && (data.mode == 1 || data.mode == 2 || data.mode == 4)) return mcmc_hip_chain(data, initial, chn, cvg);
+	if (data.ploid == 2 && (data.mode == 1 || data.mode == 2 || data.mode == 4 || (data.mode == 3 && data.prior_flag == 0)))
+		return mcmc_hip_chain(data, initial, chn, cvg);
 	if (data.ploid == 4 && data.autopoly == 1) return mcmc_hip_chain(data, initial, chn, cvg);
 	if (data.ploid == 4 && mcmc_POP_tetra_selfing) return mcmc_POP_tetra_selfing(data, initial, chn, cvg); /* -ap 0: reference code */
-	nrerror("this build of the sampler accelerates diploid modes 1, 2 and 4 (-v 1, -v 2, -v 4) and autotetraploids (-p 4 -ap 1); other modes need the reference mcmc.c");
+	nrerror("this build of the sampler accelerates diploid modes 1, 2, 3 with the uniform prior and 4 (-v 1, -v 2, -v 3 -f 0, -v 4) and autotetraploids (-p 4 -ap 1); other modes need the reference mcmc.c");
 	return chain;
 }

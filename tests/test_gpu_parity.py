@@ -57,6 +57,8 @@ SWEEP_CASES = [
     (50, 100, 3, 0.0, 2, 4, 1, 1),       # mode 4: population inbreeding coefficients
     (64, 700, 4, 0.05, 3, 4, 1, 0),      # mode 4, -e 0, three alleles, several workgroups
     (20, 60, 9, 0.02, 2, 4, 1, 1),       # mode 4, K > 8
+    (50, 100, 3, 0.0, 2, 3, 1, 1),       # mode 3: one selfing rate per individual
+    (40, 600, 4, 0.05, 3, 3, 0, 1),      # mode 3, -y 0, three alleles
 ]
 
 
@@ -69,7 +71,7 @@ def test_every_sweep_bit_exact_vs_canonical_oracle(case, sched):
     pos = ["seeds"] if sched == capi.SCHED_REPLAY else []
     h.chain_init(initd)
     o.chain_init(initd)
-    _same(h, o, ["z", "qq", "qqnum", "generation", "alpha"] + pos, "init")
+    _same(h, o, ["z", "qq", "qqnum", "generation", "alpha"] + (["self_rates"] if mode == 3 else []) + pos, "init")
     import ctypes as C
     o.lib.orc_iter_advance.argtypes = [C.c_void_p]
     h.lib.isg_iter_advance.argtypes = [C.c_void_p]
@@ -79,6 +81,11 @@ def test_every_sweep_bit_exact_vs_canonical_oracle(case, sched):
         if mode == 2:
             h.update_S_POP(); o.update_S_POP()
             _same(h, o, ["self_rates", "state"] + pos, (it, "S"))
+            h.update_G(); o.update_G()
+            _same(h, o, ["generation"] + pos, (it, "G"))
+        if mode == 3:
+            h.update_S_IND(); o.update_S_IND()
+            _same(h, o, ["self_rates"] + pos, (it, "SI"))
             h.update_G(); o.update_G()
             _same(h, o, ["generation"] + pos, (it, "G"))
         if mode == 4:
@@ -221,7 +228,7 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
         h.chain_init(initd[chn])
         f = gu.fields(next(it))           # chain n init alpha= seeds=
         assert close(h.alpha(), float.fromhex(f["alpha"]))
-        if c["mode"] == 2:
+        if c["mode"] in (2, 3):
             f = gu.fields(next(it))       # geninit
             assert orc.fnv_i32(h.generation()) == f["hgen"]
         f = gu.fields(next(it))           # zqinit
@@ -237,6 +244,13 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
                 assert close(h.self_rates(), gu.floats(line)[:K]) and gu.fields(line)["seeds"] == h.seeds(), (step, "S")
                 if c["e"] == 0:
                     assert ["st%d" % s for s in h.state()] == [t for t in line.split() if t.startswith("st")]
+                h.update_G()
+                f = gu.fields(next(it))
+                assert orc.fnv_i32(h.generation()) == f["hgen"] and f["seeds"] == h.seeds(), (step, "G")
+            if c["mode"] == 3:
+                h.update_S_IND()
+                line = next(it)
+                assert close(h.self_rates()[:4], gu.floats(line)[:4]) and gu.fields(line)["seeds"] == h.seeds(), (step, "SI")
                 h.update_G()
                 f = gu.fields(next(it))
                 assert orc.fnv_i32(h.generation()) == f["hgen"] and f["seeds"] == h.seeds(), (step, "G")
@@ -264,15 +278,15 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
                         assert close(fr[k, j, :an[j]], gu.floats(next(it)))
             # CHAIN bookkeeping as the driver does it (mcmc.c:218-226)
             if step == c["b"] - 1:
-                res = {"n": 0, "totallkh": 1.0, "qq": np.ones((N, K)), "S": np.ones(K), "gen": np.ones(N), "indv": np.ones(N)}
+                res = {"n": 0, "totallkh": 1.0, "qq": np.ones((N, K)), "S": np.ones(N if c["mode"] == 3 else K), "gen": np.ones(N), "indv": np.ones(N)}
             if step >= c["b"] and (step + 1 - c["b"]) % c["t"] == 0:
                 s = res["n"]
                 res["totallkh"] = float(_runmean(np.float64(res["totallkh"]), h.totallkh(), s))
                 res["qq"] = _runmean(res["qq"], h.qq(), s)
                 res["indv"] = _runmean(res["indv"], h.indvlkh(), s)
-                if c["mode"] in (2, 4):
+                if c["mode"] in (2, 3, 4):
                     res["S"] = _runmean(res["S"], h.self_rates(), s)
-                if c["mode"] == 2:
+                if c["mode"] in (2, 3):
                     res["gen"] = _runmean(res["gen"], h.generation().astype(float), s)
                 res["n"] += 1
                 if cnt_step < c["r"]:
@@ -287,7 +301,7 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
         if c["mode"] == 4:
             assert close(res["S"], gu.floats(next(it)), 1e-6)
             next(it)
-        if c["mode"] == 2:
+        if c["mode"] in (2, 3):
             assert close(res["S"], gu.floats(next(it)), 1e-6)
             next(it)
             assert close(res["gen"], gu.floats(next(it)), 1e-6)
@@ -345,20 +359,22 @@ def test_dropin_cli_output_equals_reference_cli_output_ploidy4(tmp_path):
     assert body(str(out)) == body(os.path.join(gu.GOLDEN, "t1_cli_output.txt"))
 
 
-def test_dropin_cli_output_equals_reference_cli_output_mode4(tmp_path):
-    """`-v 4 -e 0` (population inbreeding coefficients, adaptive independence proposals) through the drop-in"""
+@pytest.mark.parametrize("which", ["mode3", "mode4"])
+def test_dropin_cli_output_equals_reference_cli_output_other_modes(which, tmp_path):
+    """`-v 3 -f 0` (one selfing rate per individual, uniform prior) and `-v 4 -e 0` (population inbreeding
+    coefficients, adaptive independence proposals) through the drop-in"""
     exe = os.path.join(ROOT, "oracle", "_ref", "InStruct_hip")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
-    out = tmp_path / "m4.txt"
-    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out)] + gu.make_golden.MODE4_CLI
+    out = tmp_path / "m.txt"
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out)] + (gu.make_golden.MODE3_CLI if which == "mode3" else gu.make_golden.MODE4_CLI)
     log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
 
     def body(path):
         return [l for l in open(path, "rb").read().split(b"\n")
                 if not (l.strip().startswith((b"Data File:", b"Output File:")) or b"InStruct" in l and b"-d" in l)]
-    assert body(str(out)) == body(os.path.join(gu.GOLDEN, "c1_mode4_cli_output.txt"))
+    assert body(str(out)) == body(os.path.join(gu.GOLDEN, "c1_%s_cli_output.txt" % which))
 
 
 def test_dropin_k_scan_output_equals_reference(tmp_path):
