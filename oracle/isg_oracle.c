@@ -288,6 +288,24 @@ static void F_pop_terms(const orc_chain *c, const double *inbreed, int i, term_s
 		}
 	}
 }
+/* log_ld_F_indv (mcmc.c:1812-1847): the same terms with the individual's own coefficient */
+static void F_indv_terms(const orc_chain *c, double inbreed, int i, term_sink add, void *ctx)
+{
+	int j;
+	for (j = 0; j < c->p.L; j++) {
+		int a0, a1, z0, z1;
+		if (!c->valid[(long)i * c->p.L + j]) continue;
+		a0 = GENO(c, i, j, 0); a1 = GENO(c, i, j, 1);
+		z0 = ZZ(c, i, j, 0); z1 = ZZ(c, i, j, 1);
+		if (z0 == z1) {
+			add(ctx, m_log(c, genofreq_F(c, a0, a1, FREQ(c, z0, j, a0), FREQ(c, z1, j, a1), inbreed)));
+		} else {
+			add(ctx, m_log(c, FREQ(c, z0, j, a0)));
+			add(ctx, m_log(c, FREQ(c, z1, j, a1)));
+			if (a0 != a1) add(ctx, m_log(c, 2));
+		}
+	}
+}
 static void sink2(void *ctx, double v) { sum2_add((summer2 *)ctx, v); }
 static void sink1(void *ctx, double v) { sum_add((summer *)ctx, v); }
 static double log_ld_F_pop(const orc_chain *c, const double *inbreed, int i)
@@ -295,6 +313,13 @@ static double log_ld_F_pop(const orc_chain *c, const double *inbreed, int i)
 	summer2 t;
 	sum2_init(&t, c->p.accum);
 	F_pop_terms(c, inbreed, i, sink2, &t);
+	return sum2_val(&t);
+}
+static double log_ld_F_indv(const orc_chain *c, double inbreed, int i)
+{
+	summer2 t;
+	sum2_init(&t, c->p.accum);
+	F_indv_terms(c, inbreed, i, sink2, &t);
 	return sum2_val(&t);
 }
 /* log_ld_F_total (mcmc.c:1850-1868), mode 4.  Reference configuration: the per-individual values summed in order;
@@ -501,6 +526,22 @@ void orc_update_S_IND(orc_chain *c) /* mcmc.c:864-884 (mode 3, uniform prior) */
 	}
 }
 
+void orc_update_F_IND(orc_chain *c) /* mcmc.c:888-910 (mode 5, uniform prior; the coefficients live in self_rates[N]) */
+{
+	const orc_params *p = &c->p;
+	double tmp, delta0 = 0.05, mhratio;
+	int j;
+	for (j = 0; j < p->N; j++) {
+		if (keyed(c)) rng_seek(c, iter_base(c) + c->ky.offG + 2 * (uint64_t)j);
+		tmp = rng_next(c) * 2 * delta0 - delta0;
+		tmp += c->self_rates[j];
+		if (tmp <= 0.0) tmp = 0.0 - tmp;
+		if (tmp >= 1.0) tmp = 1.0 - (tmp - 1);
+		mhratio = m_exp(c, log_ld_F_indv(c, tmp, j) - log_ld_F_indv(c, c->self_rates[j], j));
+		c->self_rates[j] = (rng_next(c) < MIN2(1, mhratio)) ? tmp : c->self_rates[j];
+	}
+}
+
 void orc_update_G(orc_chain *c) /* mcmc.c:1053-1091 */
 {
 	const orc_params *p = &c->p;
@@ -577,7 +618,7 @@ void orc_cal_lkh(orc_chain *c) /* mcmc.c:1916-1942 */
 	summer t;
 	sum_init(&t, c->p.accum);
 	for (i = 0; i < c->p.N; i++) {
-		c->indvlkh[i] = (c->p.mode == 4) ? log_ld_F_pop(c, c->self_rates, i)
+		c->indvlkh[i] = (c->p.mode == 5) ? log_ld_F_indv(c, c->self_rates[i], i) : (c->p.mode == 4) ? log_ld_F_pop(c, c->self_rates, i)
 						 : log_ld_indv(c, (c->p.mode == 2 || c->p.mode == 3) ? c->generation[i] : -1, i);
 		sum_add(&t, c->indvlkh[i]);
 	}
@@ -596,6 +637,7 @@ void orc_iteration(orc_chain *c) /* mcmc.c:210-215 / 152-155 */
 		orc_update_S_IND(c);
 		orc_update_G(c);
 	}
+	if (c->p.mode == 5) orc_update_F_IND(c);
 	orc_update_ZQ(c, 0);
 	orc_update_alpha(c);
 	orc_cal_lkh(c);
@@ -636,6 +678,11 @@ void orc_chain_init_stage(orc_chain *c, const float *initd_row, int stage)
 				for (i = 0; i < p->N; i++) c->generation[i] = rgeom(c, 1 - c->self_rates[i]);
 			}
 		}
+		if (p->mode == 5) /* mcmc_INDV_inbreedcoff, mcmc.c:412-415 */
+			for (i = 0; i < p->N; i++) {
+				if (keyed(c)) rng_seek(c, 1 + 2 * (uint64_t)i);
+				c->self_rates[i] = rng_next(c);
+			}
 		if (p->mode == 4) /* mcmc_POP_inbreedcoff, mcmc.c:255-259: no generations */
 			for (i = 0; i < p->K; i++) {
 				c->self_rates[i] = initd_row[i];
@@ -717,6 +764,11 @@ static void store_chn(orc_chain *c, orc_result *r) /* mcmc.c:1320-1456 */
 		runmean(&r->qq[i], c->qq[i], r->step);
 		runmean(&r->qq2[i], c->qq[i] * c->qq[i], r->step);
 	}
+	if (p->mode == 5)
+		for (i = 0; i < p->N; i++) {
+			runmean(&r->self_rates[i], c->self_rates[i], r->step);
+			runmean(&r->self_rates2[i], c->self_rates[i] * c->self_rates[i], r->step);
+		}
 	if (p->mode == 3) {
 		for (i = 0; i < p->N; i++) {
 			runmean(&r->self_rates[i], c->self_rates[i], r->step);

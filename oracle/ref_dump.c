@@ -71,6 +71,10 @@ static void dump_chain(CHAIN *c, SEQDATA d)
 		dump_vec(G, "chain gen", c->gen, D.N);
 		dump_vec(G, "chain gen2", c->gen2, D.N);
 	}
+	if (d.mode == 5) {
+		dump_vec(G, "chain self_rates", c->inbreed, D.N);
+		dump_vec(G, "chain self_rates2", c->inbreed2, D.N);
+	}
 	if (d.mode == 4) {
 		dump_vec(G, "chain self_rates", c->inbreed, D.K);
 		dump_vec(G, "chain self_rates2", c->inbreed2, D.K);
@@ -131,6 +135,11 @@ static CHAIN run_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg, int deta
 			(unsigned long long)hash_f64v(ptr->self_rates, D.N));
 		seeds_line();
 	}
+	if (data.mode == 5) { /* mcmc_INDV_inbreedcoff, mcmc.c:412-415 (prior_flag 0) */
+		for (i = 0; i < data.totalsize; i++) ptr->inbreed[i] = ran1();
+		fprintf(G, "chain %d geninit hS=%016llx", chn, (unsigned long long)hash_f64v(ptr->inbreed, D.N));
+		seeds_line();
+	}
 	if (data.mode == 4) { /* mcmc_POP_inbreedcoff, mcmc.c:255-259 */
 		for (i = 0; i < data.popnum; i++) {
 			ptr->inbreed[i] = initial.initd[chn][i];
@@ -169,6 +178,13 @@ static CHAIN run_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg, int deta
 			seeds_line();
 			update_G(data, &ptr);
 			fprintf(G, "it %ld G hgen=%016llx", step, (unsigned long long)hash_i32v(ptr->generation, D.N));
+			seeds_line();
+		}
+		if (data.mode == 5) { /* the loop body of mcmc.c:420-433 */
+			update_F_IND(data.totalsize, &ptr, data);
+			fprintf(G, "it %ld SI", step);
+			for (i = 0; i < 4 && i < D.N; i++) fprintf(G, " %a", ptr->inbreed[i]);
+			fprintf(G, " hS=%016llx", (unsigned long long)hash_f64v(ptr->inbreed, D.N));
 			seeds_line();
 		}
 		if (data.mode == 4) { /* the loop body of mcmc.c:262-268; the inbreeding coefficients go on the S line */
