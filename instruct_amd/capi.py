@@ -166,7 +166,7 @@ class HipChain:
         return self._get("isg_get_generation", (self.N,), np.int32)
 
     def self_rates(self):
-        return self._get("isg_get_self_rates", (self.N if self.mode == 3 else self.K,), np.float64)
+        return self._get("isg_get_self_rates", (self.N if self.mode in (3, 5) else self.K,), np.float64)
 
     def state(self):
         return self._get("isg_get_state", (self.K,), np.int32)

@@ -126,6 +126,7 @@ struct isg_ctx {
 	uint64_t *d_pos;
 	unsigned *d_err;
 	double *d_S;
+	double *d_Fprop; /* mode 5: proposed coefficients */
 	double *d_tape;
 	uint64_t tape_cap, nvalid_total;
 	void *d_coop;
@@ -2092,6 +2093,8 @@ static int poly_cal_lkh(isg_ctx *c);
 static int poly_count_alleles(isg_ctx *c, int32_t *counts);
 extern "C" void isg_ctx_destroy(isg_ctx *c);
 static int indiv_update_S_IND(isg_ctx *c);
+static int indiv_update_F_IND(isg_ctx *c);
+static int indiv_cal_lkh_F(isg_ctx *c);
 static int inbreed_update_F_POP(isg_ctx *c);
 static int inbreed_cal_lkh(isg_ctx *c);
 static int inbreed_alloc(isg_ctx *c);
@@ -2104,7 +2107,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	if (cfg->P == 4) return fail("isg_ctx_create: ploidy 4 data goes through isg_ctx_create_poly");
 	if (cfg->P != 2) return fail("isg_ctx_create: only ploidy 2 and 4 are supported");
 	if (cfg->K < 1 || cfg->K > ISG_KCAP) return fail("isg_ctx_create: K must be in 1..32");
-	if (cfg->mode < 1 || cfg->mode > 4) return fail("isg_ctx_create: mode must be 1, 2, 3 or 4");
+	if (cfg->mode < 1 || cfg->mode > 5) return fail("isg_ctx_create: mode must be 1 .. 5");
 	if (cfg->N < 1 || cfg->L < 1) return fail("isg_ctx_create: empty problem");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("isg_ctx_create: no HIP device available (the MI355X path has no CPU fallback)");
@@ -2212,7 +2215,9 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	d.tab = dt;
 	DALLOC(c->d_pos, uint64_t, 4);
 	DALLOC(c->d_err, unsigned, 1);
-	DALLOC(c->d_S, double, (cfg->mode == 3 && N > ISG_KCAP) ? N : ISG_KCAP); /* mode 3: one rate per individual */
+	DALLOC(c->d_S, double, ((cfg->mode == 3 || cfg->mode == 5) && N > ISG_KCAP) ? N : ISG_KCAP); /* modes 3, 5: one value per individual */
+	c->d_Fprop = nullptr;
+	if (cfg->mode == 5) { DALLOC(c->d_Fprop, double, N); }
 	DALLOC(c->d_state, int, ISG_KCAP);
 	DALLOC(c->d_ratios, double, (size_t)N * K);
 	DALLOC(c->d_total, double, 1);
@@ -2225,7 +2230,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	c->qq.assign((size_t)N * K, 0.0);
 	c->qqnum.assign((size_t)N * K, 0);
 	c->gen.assign(N, 0);
-	c->S.assign(cfg->mode == 3 ? N : K, 0.0); /* mode 3: one selfing rate per individual */
+	c->S.assign((cfg->mode == 3 || cfg->mode == 5) ? N : K, 0.0); /* modes 3, 5: one value per individual */
 	c->state.assign(K, 0);
 	c->indvlkh.assign(N, 0.0);
 	c->cnt_h.assign((size_t)L * Amax * K, 0);
@@ -2263,7 +2268,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	DevView &d = c->d;
 	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(d.lftab); (void)hipFree(d.lltab); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
-	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S); (void)hipFree(c->d_state); (void)hipFree(c->d_ratios); (void)hipFree(c->d_total);
+	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S); (void)hipFree(c->d_Fprop); (void)hipFree(c->d_state); (void)hipFree(c->d_ratios); (void)hipFree(c->d_total);
 	prof_collect(c);
 	for (auto e : c->prof_free) (void)hipEventDestroy(e);
 	(void)hipStreamDestroy(c->stream);
@@ -2658,6 +2663,7 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 	HIPCHK(hipSetDevice(c->cfg.device));
 	if (c->poly) return poly_cal_lkh(c);
 	if (c->cfg.mode == 4) return inbreed_cal_lkh(c);
+	if (c->cfg.mode == 5) return indiv_cal_lkh_F(c);
 	DevView &d = c->d;
 	prof_begin(c);
 	if (d.lltab || (d.lftab && d.mode == 1)) hipLaunchKernelGGL((k_loglik_tab<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
@@ -2674,11 +2680,11 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 #include "isg_poly_hip.inc"
 #include "isg_inbreed_hip.inc"
 
-extern "C" int isg_update_S_IND(isg_ctx *c) /* mode 3: update_S_IND, mcmc.c:864-884 */
+extern "C" int isg_update_S_IND(isg_ctx *c) /* mode 3: update_S_IND, mcmc.c:864-884; mode 5: update_F_IND, mcmc.c:888-910 */
 {
-	if (c->poly || c->cfg.mode != 3) return fail("isg_update_S_IND: mode 3 (-v 3) only");
+	if (c->poly || (c->cfg.mode != 3 && c->cfg.mode != 5)) return fail("isg_update_S_IND: modes 3 and 5 (-v 3, -v 5) only");
 	HIPCHK(hipSetDevice(c->cfg.device));
-	return indiv_update_S_IND(c);
+	return c->cfg.mode == 3 ? indiv_update_S_IND(c) : indiv_update_F_IND(c);
 }
 
 extern "C" int isg_iteration(isg_ctx *c)
@@ -2697,6 +2703,7 @@ extern "C" int isg_iteration(isg_ctx *c)
 		if (isg_update_S_IND(c)) return 1;
 		if (isg_update_G(c)) return 1;
 	}
+	if (c->cfg.mode == 5 && isg_update_S_IND(c)) return 1;
 	if (isg_update_ZQ(c, 0)) return 1;
 	if (isg_update_alpha(c)) return 1;
 	if (isg_cal_lkh(c)) return 1;
@@ -2761,6 +2768,15 @@ extern "C" int isg_chain_init(isg_ctx *c, const float *initd)
 		HIPCHK(hipMemcpyAsync(c->d_S, c->S.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
 		c->h_gen = c->h_S = true;
+	}
+	if (c->cfg.mode == 5) { /* mcmc_INDV_inbreedcoff, mcmc.c:412-415 (prior_flag 0) */
+		for (int i = 0; i < N; i++) {
+			if (is_keyed(c)) host_seek(c, 1 + 2 * (uint64_t)i);
+			c->S[i] = host_next(c);
+		}
+		HIPCHK(hipMemcpyAsync(c->d_S, c->S.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		c->h_S = true;
 	}
 	if (c->cfg.mode == 4) { /* mcmc_POP_inbreedcoff, mcmc.c:255-259: coefficients and their states, no generations */
 		for (int k = 0; k < K; k++) {

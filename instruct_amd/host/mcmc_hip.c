@@ -394,7 +394,8 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	const int N = data.totalsize, K = data.popnum, L = data.locinum, A = data.allelenum_max;
 	double *qqflat = (double *)malloc(sizeof(double) * (size_t)N * K);
 	double *freqflat = data.print_freq == 1 ? (double *)malloc(sizeof(double) * (size_t)K * L * A) : NULL;
-	const int tetra = (data.ploid == 4), inbr = (data.ploid == 2 && data.mode == 4), indv = (data.ploid == 2 && data.mode == 3);
+	const int tetra = (data.ploid == 4), inbr = (data.ploid == 2 && data.mode == 4), indv = (data.ploid == 2 && data.mode == 3),
+		  finb = (data.ploid == 2 && data.mode == 5);
 	int i, j, k;
 
 	memset(&mchain, 0, sizeof(mchain));
@@ -417,6 +418,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 		node.self_rates = dvector(0, N - 1);
 		node.generation = ivector(0, N - 1);
 	}
+	if (finb) node.inbreed = dvector(0, N - 1); /* mode 5: one coefficient per individual */
 	if (inbr) { /* mode 4: UPMCMC.inbreed (allocate_node, mcmc.c:524-530) */
 		node.inbreed = dvector(0, K - 1);
 		node.state = ivector(0, K - 1);
@@ -446,6 +448,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 				isg_get_state(ctx, node.state);
 			}
 			if (indv) isg_get_self_rates(ctx, node.self_rates);
+			if (finb) isg_get_self_rates(ctx, node.inbreed);
 		}
 		if (data.print_iter == 1) print_info(&node, data, step, initial.update);
 		if (step == initial.burnin - 1) allocate_chn(&mchain, data);
@@ -479,6 +482,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 
 	free_dmatrix(node.qq, 0, N - 1, 0, K - 1);
 	free_dvector(node.indvlkh, 0, N - 1);
+	if (finb) free_dvector(node.inbreed, 0, N - 1);
 	if (indv) {
 		free_dvector(node.self_rates, 0, N - 1);
 		free_ivector(node.generation, 0, N - 1);
@@ -502,10 +506,10 @@ CHAIN mcmc_updating(SEQDATA data, INIT initial, int chn, CONVG *cvg) /* mcmc.c:6
 {
 	CHAIN chain;
 	memset(&chain, 0, sizeof(chain));
-	if (data.ploid == 2 && (data.mode == 1 || data.mode == 2 || data.mode == 4 || (data.mode == 3 && data.prior_flag == 0)))
+	if (data.ploid == 2 && (data.mode == 1 || data.mode == 2 || data.mode == 4 || ((data.mode == 3 || data.mode == 5) && data.prior_flag == 0)))
 		return mcmc_hip_chain(data, initial, chn, cvg);
 	if (data.ploid == 4 && data.autopoly == 1) return mcmc_hip_chain(data, initial, chn, cvg);
 	if (data.ploid == 4 && mcmc_POP_tetra_selfing) return mcmc_POP_tetra_selfing(data, initial, chn, cvg); /* -ap 0: reference code */
-	nrerror("this build of the sampler accelerates diploid modes 1, 2, 3 with the uniform prior and 4 (-v 1, -v 2, -v 3 -f 0, -v 4) and autotetraploids (-p 4 -ap 1); other modes need the reference mcmc.c");
+	nrerror("this build of the sampler accelerates diploid modes 1, 2, 4 and, with the uniform prior, 3 and 5 (-v 1, -v 2, -v 4, -v 3 -f 0, -v 5 -f 0) and autotetraploids (-p 4 -ap 1); other modes need the reference mcmc.c");
 	return chain;
 }

@@ -65,7 +65,7 @@ def load():
         lib.orc_gelman_rubin.restype = C.c_double
         lib.orc_gelman_rubin.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.orc_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        for f in ("orc_destroy", "orc_update_P", "orc_update_S_POP", "orc_update_F_POP", "orc_update_S_IND", "orc_update_G", "orc_update_alpha", "orc_cal_lkh",
+        for f in ("orc_destroy", "orc_update_P", "orc_update_S_POP", "orc_update_F_POP", "orc_update_S_IND", "orc_update_F_IND", "orc_update_G", "orc_update_alpha", "orc_cal_lkh",
                   "orc_iteration"):
             getattr(lib, f).argtypes = [C.c_void_p]
         lib.orc_update_ZQ.argtypes = [C.c_void_p, C.c_int]
@@ -128,7 +128,8 @@ class OrcChain:
     def update_P(self): self.lib.orc_update_P(self.h)
     def update_S_POP(self):
         (self.lib.orc_update_F_POP if self.mode == 4 else self.lib.orc_update_S_POP)(self.h)
-    def update_S_IND(self): self.lib.orc_update_S_IND(self.h)
+    def update_S_IND(self):
+        (self.lib.orc_update_F_IND if self.mode == 5 else self.lib.orc_update_S_IND)(self.h)
     def update_G(self): self.lib.orc_update_G(self.h)
     def update_ZQ(self, init_flag=0): self.lib.orc_update_ZQ(self.h, init_flag)
     def update_alpha(self): self.lib.orc_update_alpha(self.h)
@@ -146,7 +147,7 @@ class OrcChain:
     def qq(self): return _view(self.lib.orc_qq(self.h), (self.N, self.K), np.float64)
     def qqnum(self): return _view(self.lib.orc_qqnum(self.h), (self.N, self.K), np.float64)
     def generation(self): return _view(self.lib.orc_generation(self.h), (self.N,), np.int32)
-    def self_rates(self): return _view(self.lib.orc_self_rates(self.h), (self.N if self.mode == 3 else self.K,), np.float64)
+    def self_rates(self): return _view(self.lib.orc_self_rates(self.h), (self.N if self.mode in (3, 5) else self.K,), np.float64)
     def state(self): return _view(self.lib.orc_state(self.h), (self.K,), np.int32)
     def indvlkh(self): return _view(self.lib.orc_indvlkh(self.h), (self.N,), np.float64)
     def alpha(self): return self.lib.orc_alpha(self.h)

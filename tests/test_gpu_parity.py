@@ -59,6 +59,8 @@ SWEEP_CASES = [
     (20, 60, 9, 0.02, 2, 4, 1, 1),       # mode 4, K > 8
     (50, 100, 3, 0.0, 2, 3, 1, 1),       # mode 3: one selfing rate per individual
     (40, 600, 4, 0.05, 3, 3, 0, 1),      # mode 3, -y 0, three alleles
+    (50, 100, 3, 0.0, 2, 5, 1, 1),       # mode 5: one inbreeding coefficient per individual
+    (30, 900, 5, 0.08, 4, 5, 1, 1),      # mode 5, four alleles, missing data
 ]
 
 
@@ -71,7 +73,7 @@ def test_every_sweep_bit_exact_vs_canonical_oracle(case, sched):
     pos = ["seeds"] if sched == capi.SCHED_REPLAY else []
     h.chain_init(initd)
     o.chain_init(initd)
-    _same(h, o, ["z", "qq", "qqnum", "generation", "alpha"] + (["self_rates"] if mode == 3 else []) + pos, "init")
+    _same(h, o, ["z", "qq", "qqnum", "generation", "alpha"] + (["self_rates"] if mode in (3, 5) else []) + pos, "init")
     import ctypes as C
     o.lib.orc_iter_advance.argtypes = [C.c_void_p]
     h.lib.isg_iter_advance.argtypes = [C.c_void_p]
@@ -88,6 +90,9 @@ def test_every_sweep_bit_exact_vs_canonical_oracle(case, sched):
             _same(h, o, ["self_rates"] + pos, (it, "SI"))
             h.update_G(); o.update_G()
             _same(h, o, ["generation"] + pos, (it, "G"))
+        if mode == 5:
+            h.update_S_IND(); o.update_S_IND()   # update_F_IND
+            _same(h, o, ["self_rates"] + pos, (it, "FI"))
         if mode == 4:
             h.update_S_POP(); o.update_S_POP()   # the inbreeding coefficients travel in the selfing-rate slots
             _same(h, o, ["self_rates", "state"] + pos, (it, "F"))
@@ -231,6 +236,9 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
         if c["mode"] in (2, 3):
             f = gu.fields(next(it))       # geninit
             assert orc.fnv_i32(h.generation()) == f["hgen"]
+        if c["mode"] == 5:
+            f = gu.fields(next(it))       # initial coefficients: uniforms, exact
+            assert orc.fnv_f64(h.self_rates()) == f["hS"]
         f = gu.fields(next(it))           # zqinit
         assert orc.fnv_i32(h.z()) == f["hz"] and f["seeds"] == h.seeds()
         res, cnt_step = None, 0
@@ -254,6 +262,10 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
                 h.update_G()
                 f = gu.fields(next(it))
                 assert orc.fnv_i32(h.generation()) == f["hgen"] and f["seeds"] == h.seeds(), (step, "G")
+            if c["mode"] == 5:
+                h.update_S_IND()   # update_F_IND
+                line = next(it)
+                assert close(h.self_rates()[:4], gu.floats(line)[:4]) and gu.fields(line)["seeds"] == h.seeds(), (step, "FI")
             if c["mode"] == 4:
                 h.update_S_POP()   # update_inbreedcoff_POP: the coefficients are dumped on the S line
                 line = next(it)
@@ -278,13 +290,13 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
                         assert close(fr[k, j, :an[j]], gu.floats(next(it)))
             # CHAIN bookkeeping as the driver does it (mcmc.c:218-226)
             if step == c["b"] - 1:
-                res = {"n": 0, "totallkh": 1.0, "qq": np.ones((N, K)), "S": np.ones(N if c["mode"] == 3 else K), "gen": np.ones(N), "indv": np.ones(N)}
+                res = {"n": 0, "totallkh": 1.0, "qq": np.ones((N, K)), "S": np.ones(N if c["mode"] in (3, 5) else K), "gen": np.ones(N), "indv": np.ones(N)}
             if step >= c["b"] and (step + 1 - c["b"]) % c["t"] == 0:
                 s = res["n"]
                 res["totallkh"] = float(_runmean(np.float64(res["totallkh"]), h.totallkh(), s))
                 res["qq"] = _runmean(res["qq"], h.qq(), s)
                 res["indv"] = _runmean(res["indv"], h.indvlkh(), s)
-                if c["mode"] in (2, 3, 4):
+                if c["mode"] in (2, 3, 4, 5):
                     res["S"] = _runmean(res["S"], h.self_rates(), s)
                 if c["mode"] in (2, 3):
                     res["gen"] = _runmean(res["gen"], h.generation().astype(float), s)
@@ -298,7 +310,7 @@ def test_replay_schedule_reproduces_reference_trajectory(name):
         f = gu.fields(next(it))
         assert int(f["step"]) == res["n"] and close(res["totallkh"], float.fromhex(f["totallkh"]), 1e-6)
         assert close(res["indv"], gu.floats(next(it)), 1e-6)
-        if c["mode"] == 4:
+        if c["mode"] in (4, 5):
             assert close(res["S"], gu.floats(next(it)), 1e-6)
             next(it)
         if c["mode"] in (2, 3):
@@ -359,7 +371,7 @@ def test_dropin_cli_output_equals_reference_cli_output_ploidy4(tmp_path):
     assert body(str(out)) == body(os.path.join(gu.GOLDEN, "t1_cli_output.txt"))
 
 
-@pytest.mark.parametrize("which", ["mode3", "mode4"])
+@pytest.mark.parametrize("which", ["mode3", "mode4", "mode5"])
 def test_dropin_cli_output_equals_reference_cli_output_other_modes(which, tmp_path):
     """`-v 3 -f 0` (one selfing rate per individual, uniform prior) and `-v 4 -e 0` (population inbreeding
     coefficients, adaptive independence proposals) through the drop-in"""
@@ -367,7 +379,7 @@ def test_dropin_cli_output_equals_reference_cli_output_other_modes(which, tmp_pa
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
     out = tmp_path / "m.txt"
-    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out)] + (gu.make_golden.MODE3_CLI if which == "mode3" else gu.make_golden.MODE4_CLI)
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out)] + {"mode3": gu.make_golden.MODE3_CLI, "mode4": gu.make_golden.MODE4_CLI, "mode5": gu.make_golden.MODE5_CLI}[which]
     log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
 
