@@ -542,6 +542,51 @@ void orc_update_F_IND(orc_chain *c) /* mcmc.c:888-910 (mode 5, uniform prior; th
 	}
 }
 
+/* log_ld_indv_K (mcmc.c:1893-1914): individual i entirely in cluster k */
+static double log_ld_indv_K(const orc_chain *c, int i, int k)
+{
+	int j;
+	summer2 t;
+	sum2_init(&t, c->p.accum);
+	for (j = 0; j < c->p.L; j++) {
+		int a0, a1;
+		if (!c->valid[(long)i * c->p.L + j]) continue;
+		a0 = GENO(c, i, j, 0); a1 = GENO(c, i, j, 1);
+		sum2_add(&t, m_log(c, FREQ(c, k, j, a0)));
+		sum2_add(&t, m_log(c, FREQ(c, k, j, a1)));
+		if (a0 != a1) sum2_add(&t, m_log(c, 2));
+	}
+	return sum2_val(&t);
+}
+
+/* update_Z (mcmc.c:1094-1120), mode 0: the whole individual goes to one cluster.  zz[i] is kept in generation[i]
+ * (mode 0 has no generations) and mirrored into every allele copy of z so that the allele counts of update_P
+ * (mcmc.c:825-829) are the ordinary ones. */
+void orc_update_Z(orc_chain *c, int init_flag)
+{
+	const orc_params *p = &c->p;
+	const int K = p->K;
+	int i, j, m, zz;
+	double *tmp = malloc(sizeof(double) * K), temp = 0;
+	for (i = 0; i < p->N; i++) {
+		if (keyed(c)) rng_seek(c, init_flag ? 1 + 2 * (uint64_t)i : iter_base(c) + c->ky.offG + 2 * (uint64_t)i);
+		for (m = 0; m < K; m++) {
+			if (init_flag == 1) tmp[m] = (double)(m + 1) / K;
+			else {
+				tmp[m] = log_ld_indv_K(c, i, m);
+				if (m == 0) temp = tmp[m];
+				tmp[m] = m_exp(c, tmp[m] - temp);
+				if (m >= 1) tmp[m] += tmp[m - 1];
+			}
+		}
+		zz = disc_unif(c, tmp, K);
+		c->generation[i] = zz;
+		for (j = 0; j < p->L; j++)
+			if (c->valid[(long)i * p->L + j]) { ZZ(c, i, j, 0) = zz; ZZ(c, i, j, 1) = zz; }
+	}
+	free(tmp);
+}
+
 void orc_update_G(orc_chain *c) /* mcmc.c:1053-1091 */
 {
 	const orc_params *p = &c->p;
@@ -618,7 +663,7 @@ void orc_cal_lkh(orc_chain *c) /* mcmc.c:1916-1942 */
 	summer t;
 	sum_init(&t, c->p.accum);
 	for (i = 0; i < c->p.N; i++) {
-		c->indvlkh[i] = (c->p.mode == 5) ? log_ld_F_indv(c, c->self_rates[i], i) : (c->p.mode == 4) ? log_ld_F_pop(c, c->self_rates, i)
+		c->indvlkh[i] = (c->p.mode == 0) ? log_ld_indv_K(c, i, c->generation[i]) : (c->p.mode == 5) ? log_ld_F_indv(c, c->self_rates[i], i) : (c->p.mode == 4) ? log_ld_F_pop(c, c->self_rates, i)
 						 : log_ld_indv(c, (c->p.mode == 2 || c->p.mode == 3) ? c->generation[i] : -1, i);
 		sum_add(&t, c->indvlkh[i]);
 	}
@@ -628,6 +673,12 @@ void orc_cal_lkh(orc_chain *c) /* mcmc.c:1916-1942 */
 void orc_iteration(orc_chain *c) /* mcmc.c:210-215 / 152-155 */
 {
 	orc_update_P(c);
+	if (c->p.mode == 0) { /* mcmc.c:113-115 */
+		orc_update_Z(c, 0);
+		orc_cal_lkh(c);
+		c->iter++;
+		return;
+	}
 	if (c->p.mode == 2) {
 		orc_update_S_POP(c);
 		orc_update_G(c);
@@ -653,7 +704,7 @@ void orc_chain_init_stage(orc_chain *c, const float *initd_row, int stage)
 	if (stage == 0) {
 		c->rng.o1 = c->rng.s1; c->rng.o2 = c->rng.s2; c->rng.o3 = c->rng.s3;
 		c->iter = 0;
-		c->alpha = rng_next(c) * 10;
+		if (p->mode != 0) c->alpha = rng_next(c) * 10; /* mcmc_POP_no_admixture does not go through initial_chn */
 	} else if (stage == 1) {
 		if (p->mode == 2) {
 			for (i = 0; i < p->N; i++) {
@@ -688,6 +739,8 @@ void orc_chain_init_stage(orc_chain *c, const float *initd_row, int stage)
 				c->self_rates[i] = initd_row[i];
 				if (p->back_refl == 0) c->state[i] = dt_stat(c, c->self_rates[i]);
 			}
+	} else if (p->mode == 0) {
+		orc_update_Z(c, 1);
 	} else {
 		orc_update_ZQ(c, 1);
 	}

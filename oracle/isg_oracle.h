@@ -60,6 +60,7 @@ void orc_update_S_POP(orc_chain *c);
 void orc_update_S_IND(orc_chain *c); /* mode 3: per-individual selfing rates (self_rates has N entries then) */
 void orc_update_F_IND(orc_chain *c); /* mode 5: per-individual inbreeding coefficients (self_rates has N entries) */
 void orc_update_F_POP(orc_chain *c); /* mode 4: update_inbreedcoff_POP (the coefficients live in self_rates) */
+void orc_update_Z(orc_chain *c, int init_flag); /* mode 0: update_Z; zz[i] is returned by orc_generation() and mirrored into z */
 void orc_update_G(orc_chain *c);
 void orc_update_ZQ(orc_chain *c, int init_flag);
 void orc_update_alpha(orc_chain *c);

@@ -225,6 +225,65 @@ static CHAIN run_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg, int deta
 	return mchain;
 }
 
+/* mode 0 (mcmc_POP_no_admixture, mcmc.c:90-132): whole individuals are assigned, no alpha, no Q */
+static void flatten0(UPMCMC *p, SEQDATA d)
+{
+	long i, j, k;
+	for (i = 0; i < D.N; i++)
+		for (j = 0; j < D.L; j++)
+			for (k = 0; k < D.P; k++) zflat[(i * D.L + j) * D.P + k] = p->zz[i];
+	for (k = 0; k < D.K; k++)
+		for (j = 0; j < D.L; j++)
+			for (i = 0; i < D.Amax; i++) fflat[(k * D.L + j) * D.Amax + i] = (i < d.allelenum[j]) ? p->freq[k][j][i] : 0.0;
+}
+static CHAIN run_chain0(SEQDATA data, INIT initial, int chn, CONVG *cvg)
+{
+	int j;
+	long cnt_step = 0, step;
+	CHAIN mchain;
+	UPMCMC *ptr;
+	mchain.flag_empty_cluster = 0;
+	mchain.name_len = initial.name_len[chn];
+	mchain.chn_name = cvector(0, mchain.name_len - 1);
+	for (j = 0; j < mchain.name_len; j++) mchain.chn_name[j] = initial.chn_name[chn][j];
+	mchain.steps = (int)((initial.update - initial.burnin) / initial.thinning);
+	allocate_node(&ptr, data);
+	update_Z(&ptr, data, 1);
+	fprintf(G, "chain %d zinit hzz=%016llx", chn, (unsigned long long)hash_i32v(ptr->zz, D.N));
+	seeds_line();
+	for (step = 0; step < initial.update; step++) {
+		update_P(&ptr, data);
+		flatten0(ptr, data);
+		count_alleles_plain(&D, gflat, zflat, cflat);
+		fprintf(G, "it %ld P hcnt=%016llx hfreq=%016llx", step, (unsigned long long)hash_counts(&D, cflat), (unsigned long long)hash_freq(&D, fflat));
+		seeds_line();
+		update_Z(&ptr, data, 0);
+		fprintf(G, "it %ld Z hzz=%016llx", step, (unsigned long long)hash_i32v(ptr->zz, D.N));
+		seeds_line();
+		cal_lkh(&ptr, data);
+		fprintf(G, "it %ld L totallkh=%a hindv=%016llx\n", step, ptr->totallkh, (unsigned long long)hash_f64v(ptr->indvlkh, D.N));
+		if (step == initial.burnin - 1) allocate_chn(&mchain, data);
+		if (step >= initial.burnin && (step + 1 - initial.burnin) % initial.thinning == 0) {
+			store_chn(&mchain, ptr, data);
+			if (cnt_step < cvg->ckrep) cvg->convg_ld[chn * cvg->ckrep + cnt_step] = ptr->totallkh;
+			cnt_step++;
+		}
+	}
+	free_node(ptr, data);
+	return mchain;
+}
+static void dump_chain0(CHAIN *c)
+{
+	int i, k;
+	fprintf(G, "chain steps=%ld step=%ld flag_empty=%d totallkh=%a totallkh2=%a\n", c->steps, c->step, c->flag_empty_cluster, c->totallkh, c->totallkh2);
+	dump_vec(G, "chain indvlkh", c->indvlkh, D.N);
+	for (i = 0; i < D.N; i++) {
+		fprintf(G, "chain z %d", i);
+		for (k = 0; k < D.K; k++) fprintf(G, " %ld", c->z[i][k]);
+		fprintf(G, "\n");
+	}
+}
+
 int main(int argc, char **argv)
 {
 	SEQDATA data;
@@ -279,14 +338,15 @@ int main(int argc, char **argv)
 
 	allocate_convg(data, &cvg, c, r, NULL);
 	for (chn = 0; chn < c; chn++) {
-		chain = run_chain(data, initial, chn, &cvg, detail_every);
+		chain = (mode == 0) ? run_chain0(data, initial, chn, &cvg) : run_chain(data, initial, chn, &cvg, detail_every);
 		if (chain.flag_empty_cluster == 1) { /* InStruct.c:185-190 */
 			free_chain(&chain, data);
 			chn--;
 			continue;
 		}
 		fprintf(G, "chain %d done", chn); seeds_line();
-		dump_chain(&chain, data);
+		if (mode == 0) dump_chain0(&chain);
+		else dump_chain(&chain, data);
 		free_chain(&chain, data);
 	}
 	dump_vec(G, "convg", cvg.convg_ld, c * r);

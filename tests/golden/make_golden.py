@@ -35,6 +35,10 @@ CASES = {
     # mode 5 (-v 5): one inbreeding coefficient per individual, uniform prior (mcmc_INDV_inbreedcoff, mcmc.c:386-470)
     "m5_c1": (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 1, 1, 5, 5, (13, 4, 1972), 5, 0, 10, False),
     "m5_c1_miss": (50, 100, 3, 2, 0.05, 200, 100, 10, 2, 1, 1, 5, 5, (23, 7, 1982), 5, 0, 10, False),
+    # mode 0 (-v 0): no admixture, whole individuals assigned (mcmc_POP_no_admixture, mcmc.c:90-132)
+    "m0_c1": (50, 100, 3, 2, 0.00, 200, 100, 10, 1, 1, 1, 5, 5, (13, 4, 1972), 0, 0, 0, False),
+    "m0_c1_miss": (50, 100, 3, 2, 0.05, 200, 100, 10, 2, 1, 1, 5, 5, (24, 8, 1983), 0, 0, 0, False),
+    "m0_c1_a3": (50, 100, 3, 3, 0.02, 200, 100, 10, 1, 1, 1, 5, 5, (25, 9, 1984), 0, 0, 0, False),
     "m4_c1_miss": (50, 100, 3, 2, 0.05, 200, 100, 10, 2, 1, 1, 5, 5, (21, 5, 1980), 4, 0, 10, False),
     "c1_c2":    (50, 100, 3, 2, 0.00, 120, 60, 10, 2, 1, 1, 6, 5, (21, 7, 1999), 2, 0, 0, False),
     "c2s":      (200, 300, 5, 2, 0.01, 40, 20, 5, 1, 1, 1, 4, 4, (13, 4, 1972), 2, 0, 0, False),
@@ -57,7 +61,7 @@ def poly_data_for(name):
 
 def data_for(name):
     N, L, K, A, miss = CASES[name][:5]
-    base = {"c1_e0": "c1", "c1_y0": "c1", "c1_mode1": "c1", "c1_c2": "c1", "m4_c1": "c1", "m4_c1_e0": "c1", "m4_c1_miss": "c1_miss", "m3_c1": "c1", "m3_c1_miss": "c1_miss", "m5_c1": "c1", "m5_c1_miss": "c1_miss"}.get(name, name)
+    base = {"c1_e0": "c1", "c1_y0": "c1", "c1_mode1": "c1", "c1_c2": "c1", "m4_c1": "c1", "m4_c1_e0": "c1", "m4_c1_miss": "c1_miss", "m3_c1": "c1", "m3_c1_miss": "c1_miss", "m5_c1": "c1", "m5_c1_miss": "c1_miss", "m0_c1": "c1", "m0_c1_miss": "c1_miss", "m0_c1_a3": "c1_a3"}.get(name, name)
     seed = 20260101 + sorted(CASES).index(base)
     return synth.raw_alleles(N, L, K, 2, A, miss, seed)
 

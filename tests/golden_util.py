@@ -24,7 +24,7 @@ def case_text(name, tmpdir):
     cfg = case_args(name)
     if cfg["commit"]:
         return os.path.join(GOLDEN, name + ".txt")
-    base = {"c1_e0": "c1", "c1_y0": "c1", "c1_mode1": "c1", "c1_c2": "c1", "m4_c1": "c1", "m4_c1_e0": "c1", "m4_c1_miss": "c1_miss", "m3_c1": "c1", "m3_c1_miss": "c1_miss", "m5_c1": "c1", "m5_c1_miss": "c1_miss"}.get(name, name)
+    base = {"c1_e0": "c1", "c1_y0": "c1", "c1_mode1": "c1", "c1_c2": "c1", "m4_c1": "c1", "m4_c1_e0": "c1", "m4_c1_miss": "c1_miss", "m3_c1": "c1", "m3_c1_miss": "c1_miss", "m5_c1": "c1", "m5_c1_miss": "c1_miss", "m0_c1": "c1", "m0_c1_miss": "c1_miss", "m0_c1_a3": "c1_a3"}.get(name, name)
     if os.path.exists(os.path.join(GOLDEN, base + ".txt")):
         return os.path.join(GOLDEN, base + ".txt")
     path = os.path.join(str(tmpdir), name + ".txt")
