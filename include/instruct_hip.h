@@ -44,7 +44,7 @@ typedef struct {
 	int32_t L;         /* polymorphic loci       SEQDATA.locinum   */
 	int32_t P;         /* ploidy (2)             SEQDATA.ploid     */
 	int32_t K;         /* clusters (<= 32)       SEQDATA.popnum    */
-	int32_t mode;      /* 1 admixture, 2 population selfing rates, 3 individual selfing rates, 4 / 5 population / individual inbreeding coefficients (InStruct.c:58, mcmc.c:63-87) */
+	int32_t mode;      /* 0 no admixture, 1 admixture, 2 population selfing rates, 3 individual selfing rates, 4 / 5 population / individual inbreeding coefficients (InStruct.c:58, mcmc.c:63-87) */
 	int32_t type_freq; /* -y (InStruct.c:46) */
 	int32_t back_refl; /* -e (InStruct.c:45) */
 	int32_t rng_sched; /* ISG_SCHED_* */
@@ -69,6 +69,7 @@ int isg_chain_init(isg_ctx *ctx, const float *initd);
 /* one call per reference sweep */
 int isg_update_P(isg_ctx *ctx);                 /* mcmc.c:799-861  */
 int isg_update_S_POP(isg_ctx *ctx);             /* mcmc.c:913-983; mode 4: update_inbreedcoff_POP mcmc.c:986-1051 (coefficients in the self_rates slots) */
+int isg_update_Z(isg_ctx *ctx, int init_flag);  /* mode 0: update_Z mcmc.c:1094-1120 (zz[i] via isg_get_generation, mirrored into z) */
 int isg_update_S_IND(isg_ctx *ctx);             /* mode 3: update_S_IND mcmc.c:864-884; mode 5: update_F_IND mcmc.c:888-910 (N values in the self_rates slots) */
 int isg_update_G(isg_ctx *ctx);                 /* mcmc.c:1053-1091 (+ log_ld_indv :1726-1773) */
 int isg_update_ZQ(isg_ctx *ctx, int init_flag); /* mcmc.c:1122-1203 */

@@ -18,7 +18,7 @@ SCHED_REPLAY, SCHED_KEYED = 0, 1
 
 EXPORTS = [
     "isg_ctx_create", "isg_ctx_destroy", "isg_last_error", "isg_set_seeds", "isg_get_seeds", "isg_ran1",
-    "isg_chain_init", "isg_update_P", "isg_update_S_POP", "isg_update_S_IND", "isg_update_G", "isg_update_ZQ", "isg_update_alpha",
+    "isg_chain_init", "isg_update_P", "isg_update_S_POP", "isg_update_S_IND", "isg_update_Z", "isg_update_G", "isg_update_ZQ", "isg_update_alpha",
     "isg_cal_lkh", "isg_iteration", "isg_run", "isg_iter_advance", "isg_count_alleles", "isg_get_z", "isg_get_freq", "isg_get_qq",
     "isg_get_qqnum", "isg_get_generation", "isg_get_self_rates", "isg_get_state", "isg_get_indvlkh",
     "isg_get_alpha", "isg_get_totallkh", "isg_get_amax", "isg_set_z", "isg_set_freq", "isg_set_qq",
@@ -122,6 +122,10 @@ class HipChain:
 
     def update_S_IND(self):
         self._chk(self.lib.isg_update_S_IND(self.h))
+
+    def update_Z(self, init_flag=0):
+        """mode 0: whole individuals are assigned; zz is returned by generation()"""
+        self._chk(self.lib.isg_update_Z(self.h, init_flag))
 
     def update_G(self):
         self._chk(self.lib.isg_update_G(self.h))

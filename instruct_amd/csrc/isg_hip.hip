@@ -2092,6 +2092,8 @@ static int poly_update_ZQ(isg_ctx *c, int init_flag);
 static int poly_cal_lkh(isg_ctx *c);
 static int poly_count_alleles(isg_ctx *c, int32_t *counts);
 extern "C" void isg_ctx_destroy(isg_ctx *c);
+static int noadm_update_Z(isg_ctx *c, int init_flag);
+static int noadm_cal_lkh(isg_ctx *c);
 static int indiv_update_S_IND(isg_ctx *c);
 static int indiv_update_F_IND(isg_ctx *c);
 static int indiv_cal_lkh_F(isg_ctx *c);
@@ -2107,7 +2109,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	if (cfg->P == 4) return fail("isg_ctx_create: ploidy 4 data goes through isg_ctx_create_poly");
 	if (cfg->P != 2) return fail("isg_ctx_create: only ploidy 2 and 4 are supported");
 	if (cfg->K < 1 || cfg->K > ISG_KCAP) return fail("isg_ctx_create: K must be in 1..32");
-	if (cfg->mode < 1 || cfg->mode > 5) return fail("isg_ctx_create: mode must be 1 .. 5");
+	if (cfg->mode < 0 || cfg->mode > 5) return fail("isg_ctx_create: mode must be 0 .. 5");
 	if (cfg->N < 1 || cfg->L < 1) return fail("isg_ctx_create: empty problem");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("isg_ctx_create: no HIP device available (the MI355X path has no CPU fallback)");
@@ -2161,7 +2163,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	d.KPF = (K + 3) & ~3;
 	DALLOC(d.freqf, float, (size_t)Lp * Amax * d.KPF);
 	d.lftab = d.lltab = nullptr;
-	if (cfg->type_freq == 1) { /* (-y 0 mixes the frequencies with the individual's qq: no tables) */
+	if (cfg->type_freq == 1 || cfg->mode == 0) { /* (-y 0 mixes the frequencies with the individual's qq: no tables) */
 		const char *e = getenv("INSTRUCT_LL_TABLES");
 		if (!(e && atoi(e) == 0)) {
 			DALLOC(d.lftab, double, (size_t)L * Amax * K);
@@ -2243,6 +2245,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	c->raw_valid = true;
 	c->prof = false;
 	keyed_layout(c);
+	if (cfg->mode == 0 && !d.lftab) { isg_ctx_destroy(c); return fail("isg_ctx_create: mode 0 needs its log frequency table (INSTRUCT_LL_TABLES must not be 0)"); }
 	if (cfg->mode == 4) {
 		if (!d.lltab) { isg_ctx_destroy(c); return fail("isg_ctx_create: mode 4 needs its log-likelihood table (INSTRUCT_LL_TABLES must not be 0)"); }
 		if (inbreed_alloc(c)) { isg_ctx_destroy(c); return 1; }
@@ -2662,6 +2665,7 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 {
 	HIPCHK(hipSetDevice(c->cfg.device));
 	if (c->poly) return poly_cal_lkh(c);
+	if (c->cfg.mode == 0) return noadm_cal_lkh(c);
 	if (c->cfg.mode == 4) return inbreed_cal_lkh(c);
 	if (c->cfg.mode == 5) return indiv_cal_lkh_F(c);
 	DevView &d = c->d;
@@ -2680,6 +2684,13 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 #include "isg_poly_hip.inc"
 #include "isg_inbreed_hip.inc"
 
+extern "C" int isg_update_Z(isg_ctx *c, int init_flag) /* mode 0: update_Z, mcmc.c:1094-1120 (zz[i] is returned by isg_get_generation) */
+{
+	if (c->poly || c->cfg.mode != 0) return fail("isg_update_Z: mode 0 (-v 0) only");
+	HIPCHK(hipSetDevice(c->cfg.device));
+	return noadm_update_Z(c, init_flag);
+}
+
 extern "C" int isg_update_S_IND(isg_ctx *c) /* mode 3: update_S_IND, mcmc.c:864-884; mode 5: update_F_IND, mcmc.c:888-910 */
 {
 	if (c->poly || (c->cfg.mode != 3 && c->cfg.mode != 5)) return fail("isg_update_S_IND: modes 3 and 5 (-v 3, -v 5) only");
@@ -2694,6 +2705,12 @@ extern "C" int isg_iteration(isg_ctx *c)
 		return poly_iteration(c);
 	}
 	if (isg_update_P(c)) return 1;
+	if (c->cfg.mode == 0) { /* mcmc.c:113-115 */
+		if (isg_update_Z(c, 0)) return 1;
+		if (isg_cal_lkh(c)) return 1;
+		c->iter++;
+		return 0;
+	}
 	if (c->cfg.mode == 2) {
 		if (isg_update_S_POP(c)) return 1;
 		if (isg_update_G(c)) return 1;
@@ -2726,6 +2743,7 @@ extern "C" int isg_chain_init(isg_ctx *c, const float *initd)
 	const int N = c->cfg.N, K = c->cfg.K;
 	c->origin = c->rng;
 	c->iter = 0;
+	if (c->cfg.mode == 0) return isg_update_Z(c, 1); /* mcmc_POP_no_admixture does not draw alpha (no initial_chn) */
 	c->alpha = host_next(c) * 10;
 	if (c->cfg.mode == 2) {
 		isg_cursor cur;

@@ -502,14 +502,67 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	return mchain;
 }
 
+/* mcmc_POP_no_admixture (mcmc.c:90-132): whole individuals are assigned; no initial_chn / free_space around the loop */
+static CHAIN mcmc_hip_chain0(SEQDATA data, INIT initial, int chn, CONVG *cvg)
+{
+	isg_ctx *ctx = get_ctx(data);
+	CHAIN mchain;
+	UPMCMC node;
+	long seeds[3], cnt_step = 0, step;
+	const int N = data.totalsize, K = data.popnum, L = data.locinum, A = data.allelenum_max;
+	double *freqflat = data.print_freq == 1 ? (double *)malloc(sizeof(double) * (size_t)K * L * A) : NULL;
+	int i, j, k;
+	memset(&mchain, 0, sizeof(mchain));
+	memset(&node, 0, sizeof(node));
+	if (data.print_freq == 1) node.freq = d3tensor(0, K - 1, 0, L - 1, 0, A - 1);
+	mchain.name_len = initial.name_len[chn];
+	mchain.chn_name = cvector(0, mchain.name_len - 1);
+	for (j = 0; j < mchain.name_len; j++) mchain.chn_name[j] = initial.chn_name[chn][j];
+	mchain.steps = (int)((initial.update - initial.burnin) / initial.thinning);
+	fprintf(stdout, "\n\n%s Starts:\n", mchain.chn_name);
+	node.zz = ivector(0, N - 1);
+	node.indvlkh = dvector(0, N - 1);
+	read_host_seeds(seeds);
+	if (isg_set_seeds(ctx, seeds[0], seeds[1], seeds[2])) hip_fail("isg_set_seeds");
+	if (isg_chain_init(ctx, initial.initd[chn])) hip_fail("isg_chain_init");
+	for (step = 0; step < initial.update; step++) {
+		const int stored = (step >= initial.burnin && (step + 1 - initial.burnin) % initial.thinning == 0);
+		if (isg_iteration(ctx)) hip_fail("isg_iteration");
+		if (stored || data.print_iter == 1) isg_get_totallkh(ctx, &node.totallkh);
+		if (data.print_iter == 1) print_info(&node, data, step, initial.update);
+		if (step == initial.burnin - 1) allocate_chn(&mchain, data);
+		if (stored) {
+			isg_get_indvlkh(ctx, node.indvlkh);
+			isg_get_generation(ctx, node.zz); /* the ABI returns the cluster of each individual in the generation slots */
+			if (data.print_freq == 1) {
+				if (isg_get_freq(ctx, freqflat)) hip_fail("isg_get_freq");
+				for (k = 0; k < K; k++)
+					for (j = 0; j < L; j++)
+						for (i = 0; i < data.allelenum[j]; i++) node.freq[k][j][i] = freqflat[((size_t)k * L + j) * A + i];
+			}
+			store_chn(&mchain, &node, data);
+			if (cnt_step < cvg->ckrep) cvg->convg_ld[chn * cvg->ckrep + cnt_step] = node.totallkh;
+			cnt_step++;
+		}
+	}
+	isg_get_seeds(ctx, seeds);
+	setseeds((int)seeds[0], (int)seeds[1], (int)seeds[2]);
+	free_ivector(node.zz, 0, N - 1);
+	free_dvector(node.indvlkh, 0, N - 1);
+	if (data.print_freq == 1) free_d3tensor(node.freq, 0, K - 1, 0, L - 1, 0, A - 1);
+	free(freqflat);
+	return mchain;
+}
+
 CHAIN mcmc_updating(SEQDATA data, INIT initial, int chn, CONVG *cvg) /* mcmc.c:63-87 */
 {
 	CHAIN chain;
 	memset(&chain, 0, sizeof(chain));
+	if (data.ploid == 2 && data.mode == 0) return mcmc_hip_chain0(data, initial, chn, cvg);
 	if (data.ploid == 2 && (data.mode == 1 || data.mode == 2 || data.mode == 4 || ((data.mode == 3 || data.mode == 5) && data.prior_flag == 0)))
 		return mcmc_hip_chain(data, initial, chn, cvg);
 	if (data.ploid == 4 && data.autopoly == 1) return mcmc_hip_chain(data, initial, chn, cvg);
 	if (data.ploid == 4 && mcmc_POP_tetra_selfing) return mcmc_POP_tetra_selfing(data, initial, chn, cvg); /* -ap 0: reference code */
-	nrerror("this build of the sampler accelerates diploid modes 1, 2, 4 and, with the uniform prior, 3 and 5 (-v 1, -v 2, -v 4, -v 3 -f 0, -v 5 -f 0) and autotetraploids (-p 4 -ap 1); other modes need the reference mcmc.c");
+	nrerror("this build of the sampler accelerates diploid modes 0, 1, 2, 4 and, with the uniform prior, 3 and 5 (-v 0 .. -v 5, -f 0) and autotetraploids (-p 4 -ap 1); other modes need the reference mcmc.c");
 	return chain;
 }

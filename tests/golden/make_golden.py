@@ -108,6 +108,9 @@ def main():
     cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "c1.txt"), "-o", os.path.join(HERE, "c1_mode5_cli_output.txt")] + MODE5_CLI
     with open(os.devnull, "w") as devnull:
         subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
+    cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "c1.txt"), "-o", os.path.join(HERE, "c1_mode0_cli_output.txt")] + MODE0_CLI
+    with open(os.devnull, "w") as devnull:
+        subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
     # same for the ploidy 4 driver (mcmc_POP_tetra_selfing)
     cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "t1.txt"), "-o", os.path.join(HERE, "t1_cli_output.txt")] + TETRA_CLI
     with open(os.devnull, "w") as devnull:
@@ -126,6 +129,9 @@ MODE3_CLI = ["-K", "3", "-L", "100", "-N", "50", "-p", "2", "-u", "200", "-b", "
 
 MODE5_CLI = ["-K", "3", "-L", "100", "-N", "50", "-p", "2", "-u", "200", "-b", "100", "-t", "10", "-c", "2", "-v", "5", "-f", "0", "-g", "1", "-r", "5",
              "-j", "5", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "0"]
+
+MODE0_CLI = ["-K", "3", "-L", "100", "-N", "50", "-p", "2", "-u", "200", "-b", "100", "-t", "10", "-c", "2", "-v", "0", "-g", "1", "-r", "5",
+             "-j", "5", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "1"]
 
 TETRA_CLI = ["-K", "3", "-L", "40", "-N", "60", "-p", "4", "-ap", "1", "-af", "1", "-u", "60", "-b", "30", "-t", "5", "-c", "2",
              "-v", "2", "-g", "1", "-r", "4", "-j", "4", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "0"]

@@ -69,6 +69,7 @@ def load():
                   "orc_iteration"):
             getattr(lib, f).argtypes = [C.c_void_p]
         lib.orc_update_ZQ.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_update_Z.argtypes = [C.c_void_p, C.c_int]
         lib.orc_chain_init.argtypes = [C.c_void_p, C.c_void_p]
         lib.orc_get_seeds.argtypes = [C.c_void_p, C.c_void_p]
         lib.orc_count_alleles.argtypes = [C.c_void_p, C.c_void_p]
@@ -132,6 +133,7 @@ class OrcChain:
         (self.lib.orc_update_F_IND if self.mode == 5 else self.lib.orc_update_S_IND)(self.h)
     def update_G(self): self.lib.orc_update_G(self.h)
     def update_ZQ(self, init_flag=0): self.lib.orc_update_ZQ(self.h, init_flag)
+    def update_Z(self, init_flag=0): self.lib.orc_update_Z(self.h, init_flag)
     def update_alpha(self): self.lib.orc_update_alpha(self.h)
     def cal_lkh(self): self.lib.orc_cal_lkh(self.h)
     def iteration(self): self.lib.orc_iteration(self.h)

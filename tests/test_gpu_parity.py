@@ -108,6 +108,86 @@ def test_every_sweep_bit_exact_vs_canonical_oracle(case, sched):
     h.close()
 
 
+@pytest.mark.parametrize("sched", [capi.SCHED_REPLAY, capi.SCHED_KEYED])
+@pytest.mark.parametrize("case", [(50, 100, 3, 0.0, 2), (40, 1300, 6, 0.08, 3), (12, 70, 20, 0.3, 4)])
+def test_mode0_every_sweep_bit_exact_vs_canonical_oracle(case, sched):
+    """mode 0 (-v 0, no admixture): update_P / update_Z / cal_lkh; zz[i] travels in the generation slots"""
+    N, L, K, miss, nall = case
+    geno, an, mi = synth.code_diploid(synth.raw_alleles(N, L, K, 2, nall, miss, 17))
+    h, o, initd = _pair(geno, an, mi, K, sched, 0)
+    pos = ["seeds"] if sched == capi.SCHED_REPLAY else []
+    h.chain_init(initd)
+    o.chain_init(initd)
+    _same(h, o, ["z", "generation"] + pos, "init")
+    import ctypes as C
+    o.lib.orc_iter_advance.argtypes = [C.c_void_p]
+    h.lib.isg_iter_advance.argtypes = [C.c_void_p]
+    for it in range(3):
+        h.update_P(); o.update_P()
+        _same(h, o, ["count_alleles", "freq"] + pos, (it, "P"))
+        h.update_Z(0); o.update_Z(0)
+        _same(h, o, ["z", "generation"] + pos, (it, "Z"))
+        h.cal_lkh(); o.cal_lkh()
+        _same(h, o, ["indvlkh", "totallkh"], (it, "L"))
+        o.lib.orc_iter_advance(o.h)
+        h.lib.isg_iter_advance(h.h)
+    for it in range(2):
+        h.iteration(); o.iteration()
+        _same(h, o, ["z", "generation", "freq", "indvlkh", "totallkh"] + pos, ("iteration", it))
+    assert o.error() == 0
+    h.close()
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(gu.CASES) if gu.case_args(n)["mode"] == 0])
+def test_mode0_replay_schedule_reproduces_reference_trajectory(name):
+    c = gu.case_args(name)
+    geno, an, mi = gu.case_data(name)
+    lines = gu.parse(os.path.join(gu.GOLDEN, name + ".golden"))
+    K, N = c["K"], geno.shape[0]
+    h = capi.HipChain(geno, an, mi, K, mode=0, rng_sched=capi.SCHED_REPLAY)
+    h.setseeds(*c["seeds"])
+    initd = np.array([[h.ran1() for _ in range(K)] for _ in range(c["c"])], dtype=np.float32)
+    it = iter(lines)
+    cur = next(it)
+    while not cur.startswith("init "):
+        cur = next(it)
+    assert gu.fields(cur)["seeds"] == h.seeds()
+
+    def close(a, b, tol=1e-9):
+        a, b = np.atleast_1d(np.asarray(a, dtype=float)), np.atleast_1d(np.asarray(b, dtype=float))
+        return a.shape == b.shape and bool(np.all((a == b) | (np.abs(a - b) <= tol * np.abs(b))))
+    convg = []
+    for chn in range(c["c"]):
+        h.chain_init(initd[chn])
+        f = gu.fields(next(it))
+        assert orc.fnv_i32(h.generation()) == f["hzz"] and f["seeds"] == h.seeds()
+        zc, nstore = np.zeros((N, K), dtype=np.int64), 0
+        for step in range(c["u"]):
+            h.update_P()
+            f = gu.fields(next(it))
+            assert _counts_hash(h.count_alleles(), an) == f["hcnt"] and f["seeds"] == h.seeds(), (step, "P")
+            h.update_Z(0)
+            f = gu.fields(next(it))
+            assert orc.fnv_i32(h.generation()) == f["hzz"] and f["seeds"] == h.seeds(), (step, "Z")
+            h.cal_lkh()
+            f = gu.fields(next(it))
+            assert close(h.totallkh(), float.fromhex(f["totallkh"])), (step, "L")
+            if step >= c["b"] and (step + 1 - c["b"]) % c["t"] == 0:
+                zc[np.arange(N), h.generation()] += 1
+                if nstore < c["r"]:
+                    convg.append(h.totallkh())
+                nstore += 1
+        f = gu.fields(next(it))  # chain n done
+        assert f["seeds"] == h.seeds()
+        next(it)                 # chain steps= ...
+        next(it)                 # chain indvlkh
+        for i in range(N):
+            assert [int(x) for x in next(it).split()[3:]] == list(zc[i])   # posterior assignment counts (CHAIN.z)
+    line = next(it)
+    assert line.startswith("convg") and close(convg, gu.floats(line))
+    h.close()
+
+
 EDGE_CASES = [
     # N, L, K, alleles, missing, note
     (40, 60, 6, 12, 0.05),     # microsatellite-like: count tile variant <256 lanes, 1 locus per lane>
@@ -202,7 +282,7 @@ def _runmean(m, x, step):
     return np.where(m != 0, m * ((step + x / np.where(m != 0, m, 1)) / (1 + step)), x / (1 + step))
 
 
-@pytest.mark.parametrize("name", sorted(gu.CASES))
+@pytest.mark.parametrize("name", [n for n in sorted(gu.CASES) if gu.case_args(n)["mode"] != 0])
 def test_replay_schedule_reproduces_reference_trajectory(name):
     """Golden trajectories come from the reference's own sweeps (oracle/ref_dump.c)."""
     c = gu.case_args(name)
@@ -371,7 +451,7 @@ def test_dropin_cli_output_equals_reference_cli_output_ploidy4(tmp_path):
     assert body(str(out)) == body(os.path.join(gu.GOLDEN, "t1_cli_output.txt"))
 
 
-@pytest.mark.parametrize("which", ["mode3", "mode4", "mode5"])
+@pytest.mark.parametrize("which", ["mode0", "mode3", "mode4", "mode5"])
 def test_dropin_cli_output_equals_reference_cli_output_other_modes(which, tmp_path):
     """`-v 3 -f 0` (one selfing rate per individual, uniform prior) and `-v 4 -e 0` (population inbreeding
     coefficients, adaptive independence proposals) through the drop-in"""
@@ -379,7 +459,7 @@ def test_dropin_cli_output_equals_reference_cli_output_other_modes(which, tmp_pa
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
     out = tmp_path / "m.txt"
-    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out)] + {"mode3": gu.make_golden.MODE3_CLI, "mode4": gu.make_golden.MODE4_CLI, "mode5": gu.make_golden.MODE5_CLI}[which]
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out)] + {"mode0": gu.make_golden.MODE0_CLI, "mode3": gu.make_golden.MODE3_CLI, "mode4": gu.make_golden.MODE4_CLI, "mode5": gu.make_golden.MODE5_CLI}[which]
     log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
 
