@@ -97,7 +97,7 @@ struct InbreedCtx;
 struct isg_ctx {
 	isg_config cfg;
 	PolyCtx *poly = nullptr; /* ploidy 4 state (isg_poly_hip.inc) */
-	InbreedCtx *inb = nullptr; /* mode 4 state (isg_inbreed_hip.inc) */
+	InbreedCtx *inb = nullptr; /* mode 4 state (isg_modes_hip.inc) */
 	DevView d;
 	int Amax;
 	hipStream_t stream;
@@ -2682,7 +2682,7 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 }
 
 #include "isg_poly_hip.inc"
-#include "isg_inbreed_hip.inc"
+#include "isg_modes_hip.inc"
 
 extern "C" int isg_update_Z(isg_ctx *c, int init_flag) /* mode 0: update_Z, mcmc.c:1094-1120 (zz[i] is returned by isg_get_generation) */
 {
