@@ -264,6 +264,34 @@ def test_long_run_stays_bit_exact(mode, sched):
     h.close()
 
 
+def test_config2_twenty_iterations_bit_exact():
+    """BASELINE config 2 (N=2000, L=1000, K=5, mode 2), replay schedule: Z, allele counts, generations, qq and the
+    stream position after each of 20 iterations against the canonical oracle (SURVEY 8d parity gate)."""
+    geno, an, mi = synth.make_diploid(2000, 1000, 5)
+    h, o, initd = _pair(geno, an, mi, 5, capi.SCHED_REPLAY, 2)
+    h.chain_init(initd)
+    o.chain_init(initd)
+    for it in range(20):
+        h.iteration()
+        o.iteration()
+        _same(h, o, ["z", "count_alleles", "generation", "qq", "self_rates", "alpha", "totallkh", "seeds"], it)
+    h.close()
+
+
+def test_config3_two_iterations_bit_exact(full_size):
+    """BASELINE config 3 (N=10000, L=5000, K=5), replay schedule, against the canonical oracle at full size
+    (the oracle needs ~10 s per iteration here, hence two)."""
+    geno, an, mi = full_size
+    h, o, initd = _pair(geno, an, mi, 5, capi.SCHED_REPLAY, 2)
+    h.chain_init(initd)
+    o.chain_init(initd)
+    for it in range(2):
+        h.iteration()
+        o.iteration()
+        _same(h, o, ["z", "count_alleles", "generation", "qq", "self_rates", "alpha", "totallkh", "seeds"], it)
+    h.close()
+
+
 def test_checkpoint_and_resume_continue_the_same_chain():
     """The sampler state at an iteration boundary is (z, qq, generation, selfing rates, alpha, stream position):
     a new context restored from it through the setters continues bit-identically (the reference cannot resume)."""
