@@ -706,6 +706,7 @@ struct ZqShared {
 	unsigned amask[2][ISG_KCAP]; /* cooperative kernel: per gamma, bit o = the attempt at even offset o is accepted ... */
 	unsigned rmask[2][ISG_KCAP]; /* ... / did NOT consume exactly two uniforms (double buffered by individual parity) */
 	int ghist[2][ISG_KCAP];      /* cooperative kernel: the other workgroups' bucket counts */
+	int hist3[3][ISG_KCAP], ghist3[3][ISG_KCAP]; /* k_zq_spec: the same, triple buffered (its Dirichlet has no barrier) */
 };
 
 /*
@@ -1595,6 +1596,114 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
 }
 
 /*
+ * The Dirichlet of k_zq_spec (K <= 8): every WAVE evaluates the attempt table for itself -- lane (m, d) the attempt of
+ * gamma m at stream offset m + d (gamma m cannot start before m earlier gammas took an attempt each; 64 / K offsets
+ * per gamma) -- and gets the accepted / irregular masks from two ballots, so the walk needs no LDS round trip and no
+ * barrier.  Walks that leave the table (1 % at K = 5) are redone sequentially by lane 0 of each wave.
+ * Counts: sh.hist3[buf] + sh.ghist3[buf]; the caller's barrier made them complete.
+ */
+template <int KMAX>
+__device__ __forceinline__ unsigned dirichlet_wave(const DevView &d, ZqShared &sh, int i, const isg_wh &cur, unsigned long long dstart_off,
+						  double alpha, int buf, const double *dtape, bool writer)
+{
+	const int K = d.K, lane = (int)lane_id(), D = 64 / K;
+	const int m = (lane < K * D) ? lane / D : K - 1, dd = lane - m * D;
+	const bool act = lane < K * D;
+	const int cnt = sh.hist3[buf][m] + sh.ghist3[buf][m];
+	const double a = (double)cnt + alpha;
+	isg_cursor c;
+	c.used = 0;
+	c.tape = dtape ? dtape + 2 * (m + dd) : nullptr;
+	if (!dtape) c.s = isg_wh_jump(&sh.tab, cur, dstart_off + 2ull * (unsigned)(m + dd));
+	double r = -1;
+	if (act) {
+		const double pu0 = isg_cur_next(&c), pu1 = isg_cur_next(&c);
+		if (a < 1) r = rgamma1_try_pre(pu0, pu1, a);
+		else if (a > 1) r = rgamma2_try_dev(&c, pu0, pu1, a);
+		else c.used = 255; /* shape 1: odd consumption */
+	}
+	const unsigned long long A = __ballot(act && !(r < 0)), I = __ballot(act && c.used != 2);
+	const unsigned dmask = (D >= 32) ? 0xffffffffu : ((1u << D) - 1u);
+	unsigned fo = 0; /* attempts consumed so far = stream offset / 2 */
+	bool bad = false;
+	double v = 0.0;  /* lane mm < K ends up with gamma mm's value */
+#pragma unroll
+	for (int mm = 0; mm < KMAX; mm++) {
+		if (mm < K) {
+			const unsigned Am = (unsigned)(A >> (mm * D)) & dmask, Im = (unsigned)(I >> (mm * D)) & dmask;
+			const unsigned rel = fo - (unsigned)mm; /* fo >= mm always */
+			const unsigned rest = (rel < (unsigned)D) ? ((Am | Im) >> rel) : 0u;
+			const unsigned e = rel + (rest ? (unsigned)__builtin_ctz(rest) : 0u);
+			bad |= (rest == 0u) || (((Im >> (e & 31u)) & 1u) != 0u);
+			const double val = readlane_f64(r, (mm * D + (int)(e < (unsigned)D ? e : 0u)) & 63);
+			v = (lane == mm) ? val : v;
+			fo = (unsigned)mm + e + 1u;
+		}
+	}
+	unsigned used = 2u * fo;
+	if (bad) { /* an irregular attempt on the path (a retry inside it: more than two uniforms): the general walk */
+		const unsigned ul = (unsigned)c.used;
+		unsigned go = 0;
+		int gm = 0;
+		bool ok = true;
+		while (gm < K) {
+			const unsigned Am = (unsigned)(A >> (gm * D)) & dmask, Im = (unsigned)(I >> (gm * D)) & dmask;
+			const unsigned rel = go - (unsigned)gm;
+			if (rel >= (unsigned)D) { ok = false; break; }
+			const unsigned rest = (Am | Im) >> rel;
+			if (rest == 0u) { ok = false; break; }
+			const unsigned e = rel + (unsigned)__builtin_ctz(rest);
+			const int idx = gm * D + (int)e;
+			unsigned step = 1;
+			if ((Im >> e) & 1u) {
+				const unsigned u = (unsigned)__builtin_amdgcn_readlane((int)ul, idx);
+				if (u == 255u || (u & 1u)) { ok = false; break; }
+				step = u >> 1;
+			}
+			go = (unsigned)gm + e + step;
+			if ((Am >> e) & 1u) {
+				const double val = readlane_f64(r, idx);
+				v = (lane == gm) ? val : v;
+				gm++;
+			}
+		}
+		bad = !ok;
+		used = 2u * go;
+	}
+	if (bad) { /* wave-uniform: the plain loop from the Dirichlet's first position */
+		double g[KMAX];
+		unsigned u = 0;
+		if (lane == 0) {
+			isg_cursor q;
+			q.used = 0;
+			q.tape = nullptr;
+			q.s = isg_wh_jump(&sh.tab, cur, dstart_off);
+#pragma unroll
+			for (int mm = 0; mm < KMAX; mm++) g[mm] = (mm < K) ? isg_rgamma(&q, (double)(sh.hist3[buf][mm] + sh.ghist3[buf][mm]) + alpha) : 0.0;
+			u = q.used;
+		} else {
+#pragma unroll
+			for (int mm = 0; mm < KMAX; mm++) g[mm] = 0.0;
+		}
+		used = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
+#pragma unroll
+		for (int mm = 0; mm < KMAX; mm++) {
+			const double val = readlane_f64(g[mm], 0);
+			v = (lane == mm) ? val : v;
+		}
+	}
+	if (writer) { /* qq[i] = g / sum with the sum taken in stream order (random.c:272-279) */
+		double sum = 0;
+		for (int k2 = 0; k2 < K; k2++) sum += readlane_f64(v, k2);
+		if (lane < K) {
+			d.qq[(size_t)i * K + lane] = v / sum;
+			d.qqnum[(size_t)i * K + lane] = sh.hist3[buf][lane] + sh.ghist3[buf][lane];
+		}
+	}
+	return used;
+}
+
+/*
  * k_zq_spec: k_zq_coop with the Z draws taken off the critical path (single pass: one locus per lane, K <= 8).
  * Individual i+1 starts used_i uniforms behind the end of individual i's draws, and used_i = 2 K + 2 c where c is
  * the number of rejected gamma attempts of i's Dirichlet -- almost always 0..3.  While the counts of individual i
@@ -1624,6 +1733,10 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 			(&sh.amask[0][0])[t] = 0;
 			(&sh.rmask[0][0])[t] = 0;
 			(&sh.ghist[0][0])[t] = 0;
+		}
+		if (t < 3 * ISG_KCAP) {
+			(&sh.hist3[0][0])[t] = 0;
+			(&sh.ghist3[0][0])[t] = 0;
 		}
 	}
 	__syncthreads();
@@ -1693,7 +1806,7 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 	bool cvalid = false;
 	for (int i = 0; i < d.N; i++) {
 		const unsigned tag = (unsigned)(i % 65535) + 1u;
-		const int slot = i & (ISG_COOP_RING - 1), par = i & 1;
+		const int slot = i & (ISG_COOP_RING - 1), buf = i % 3;
 		if (touch == -1.0) cb->overflow_flag = 2;
 		const int nvalid = __builtin_amdgcn_readfirstlane(cl.nvv), nnvalid = __builtin_amdgcn_readfirstlane(nl.nvv);
 		const unsigned long long offi = off;
@@ -1766,13 +1879,13 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 			if (lane == 0) {
 #pragma unroll
 				for (int m = 0; m < KMAX; m++)
-					if (m < K && wcnt[m]) atomicAdd(&sh.hist[par][m], wcnt[m]);
+					if (m < K && wcnt[m]) atomicAdd(&sh.hist3[buf][m], wcnt[m]);
 			}
 			lds_barrier();
 			if (t < W) { /* `pack` counts of `bits` bits per word */
 				unsigned long long v = (unsigned long long)tag << 48;
 				for (int c3 = 0; c3 < pack; c3++)
-					if (pack * t + c3 < K) v |= (unsigned long long)(sh.hist[par][pack * t + c3] & ((1 << bits) - 1)) << (bits * c3);
+					if (pack * t + c3 < K) v |= (unsigned long long)(sh.hist3[buf][pack * t + c3] & ((1 << bits) - 1)) << (bits * c3);
 				if (local) st_xcd(&cb->gran[slot][g * W + t], v); else st_agent(&cb->gran[slot][g * W + t], v);
 			}
 		}
@@ -1811,15 +1924,21 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 				for (int c3 = 0; c3 < pack; c3++) {
 					const int m = pack * w + c3;
 					const int c = (int)((v >> (bits * c3)) & ((1 << bits) - 1));
-					if (m < K && c) atomicAdd(&sh.ghist[par][m], c);
+					if (m < K && c) atomicAdd(&sh.ghist3[buf][m], c);
 				}
 			}
 		}
 		lds_barrier();
 		STAMP(i, 3);
+		/* the buffer of individual i + 2 (last read before this barrier, next written after the next one) */
+		if (t < KMAX) {
+			sh.hist3[(i + 2) % 3][t] = 0;
+			sh.ghist3[(i + 2) % 3][t] = 0;
+		}
 		const unsigned used = 2u * (unsigned)nvalid +
-			dirichlet_coop<BLOCK, KMAX>(d, sh, i, cur, offi + 2ull * (unsigned)nvalid, alpha, par,
-						    covered ? d.tape + offi + 2ull * (unsigned)nvalid : nullptr, writer);
+			dirichlet_wave<KMAX>(d, sh, i, cur, offi + 2ull * (unsigned)nvalid, alpha, buf,
+					     covered ? d.tape + offi + 2ull * (unsigned)nvalid : nullptr, writer);
+		STAMP(i, 5);
 		off += used;
 		cl = nl;
 		nl = ml;

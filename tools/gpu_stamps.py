@@ -38,8 +38,8 @@ elif os.environ.get("INSTRUCT_ZQ_COOP", "1") != "0":
     order = [0, 6, 7, 1, 2, 3, 4, 5]
     names = ["top->loads issued", "->buckets done", "->counts+store", "->published", "->gathered", "->attempts", "->walk"]
     if os.environ.get("INSTRUCT_ZQ_SPEC", "1") != "0":
-        order = [0, 1, 2, 6, 3, 4, 5]
-        names = ["top->z picked+stored", "->published", "->candidates drawn", "->gathered", "->attempts", "->walk"]
+        order = [0, 1, 2, 6, 3, 5]
+        names = ["top->z picked+stored", "->published", "->candidates drawn", "->gathered", "->Dirichlet (per wave)"]
     if "-DISG_EXP_XWAIT" in extra:
         order = [0, 2, 3, 6, 7, 1, 4, 5]
         names = ["top->x issued", "->x arrived", "->prefetch issued", "->buckets", "->counts+store", "->(publish+gather+attempts)", "->walk"]
