@@ -17,14 +17,15 @@ for sched in (capi.SCHED_REPLAY, capi.SCHED_KEYED):
     h.run(iters)
     print("diploid sched", sched, h.totallkh(), flush=True)
     h.close()
-if len(sys.argv) <= 2 or sys.argv[2] != "no-tetra":
+if len(sys.argv) <= 2 or sys.argv[2] != "no-tetra":  # both schedules
     K = 10
     raw = synth.raw_alleles(1000, 20000, K, 4, 4, 0.05, 20260105)
     obs, alleleid, allelenum = synth.code_tetraploid_fast(raw)
     obs, alleleid = np.tile(obs, (10, 1, 1)), np.tile(alleleid, (10, 1))
-    ch = capi.HipPolyChain(obs, alleleid, allelenum, K)
-    ch.setseeds(13, 4, 1972)
-    ch.chain_init(np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32))
-    ch.run(iters)
-    print("tetra", ch.totallkh(), flush=True)
-    ch.close()
+    for sched in (capi.SCHED_REPLAY, capi.SCHED_KEYED):
+        ch = capi.HipPolyChain(obs, alleleid, allelenum, K, rng_sched=sched)
+        ch.setseeds(13, 4, 1972)
+        ch.chain_init(np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32))
+        ch.run(iters)
+        print("tetra sched", sched, ch.totallkh(), flush=True)
+        ch.close()
