@@ -255,7 +255,7 @@ def main():
         ch.setseeds(*seeds)
         ch.chain_init(np.array([ch.ran1() for _ in range(K)], dtype=np.float32))
         dt, lk, prof = timed_steps(ch, args.steps, args.warmup, world)
-        zq = next(k for k in ("k_zq_spec", "k_zq_coop", "k_zq_chain") if k in prof) if sched == capi.SCHED_REPLAY else "k_zq_keyed"
+        zq = next(k for k in ("k_zq_pipe", "k_zq_spec", "k_zq_coop", "k_zq_chain") if k in prof) if sched == capi.SCHED_REPLAY else "k_zq_keyed"
         # update_ZQ launch: reads the genotype byte and writes the Z byte of every allele copy
         rl = roofline(prof, zq, 2 * N * L * P, traffic.get(zq))
         ckrep = min(len(lk), 20)

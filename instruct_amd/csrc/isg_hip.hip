@@ -133,6 +133,10 @@ struct isg_ctx {
 	int coop; /* 1: several workgroups per individual in the replay-schedule ZQ kernel */
 	int spec; /* 1: ... with the next individual's Z drawn ahead for the likely start positions (INSTRUCT_ZQ_SPEC=0 disables) */
 	int xcd;  /* 1: try to place the cooperating workgroups on one XCD (INSTRUCT_ZQ_XCD=1 enables) */
+	int pipe; /* 1: draw waves + one control wave per workgroup (k_zq_pipe; INSTRUCT_ZQ_PIPE=0 disables) */
+	int pipe_xcd; /* 1: its workgroups on one XCD when they fit (INSTRUCT_ZQ_PIPE_XCD=0 disables) */
+	unsigned long long *d_pipe = nullptr; /* its granules (one line per publishing wave) */
+	size_t pipe_cap = 0;
 	int *d_state;
 	double *d_ratios, *d_total;
 	std::vector<double> ratios_h;
@@ -1604,7 +1608,7 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
  */
 template <int KMAX>
 __device__ __forceinline__ unsigned dirichlet_wave(const DevView &d, ZqShared &sh, int i, const isg_wh &cur, unsigned long long dstart_off,
-						  double alpha, int buf, const double *dtape, bool writer)
+						  double alpha, int buf, const double *dtape, bool writer, bool pre = false, double ppu0 = 0.0, double ppu1 = 0.0)
 {
 	const int K = d.K, lane = (int)lane_id(), D = 64 / K;
 	const int m = (lane < K * D) ? lane / D : K - 1, dd = lane - m * D;
@@ -1617,7 +1621,15 @@ __device__ __forceinline__ unsigned dirichlet_wave(const DevView &d, ZqShared &s
 	if (!dtape) c.s = isg_wh_jump(&sh.tab, cur, dstart_off + 2ull * (unsigned)(m + dd));
 	double r = -1;
 	if (act) {
-		const double pu0 = isg_cur_next(&c), pu1 = isg_cur_next(&c);
+		double pu0, pu1;
+		if (pre && dtape) { /* the caller fetched this lane's first two uniforms (dtape[2 (m + dd)], [.. + 1]) ahead of time */
+			pu0 = ppu0;
+			pu1 = ppu1;
+			c.used = 2;
+		} else {
+			pu0 = isg_cur_next(&c);
+			pu1 = isg_cur_next(&c);
+		}
 		if (a < 1) r = rgamma1_try_pre(pu0, pu1, a);
 		else if (a > 1) r = rgamma2_try_dev(&c, pu0, pu1, a);
 		else c.used = 255; /* shape 1: odd consumption */
@@ -1944,6 +1956,314 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 		nl = ml;
 	}
 	if (g == 0 && t == 0) *pos_out = off;
+}
+
+/* sum of x over the 64 lanes, as a wave-uniform value: rotations inside the rows of 16 lanes (every lane of a row
+ * ends up with the row's sum), then the four rows through SGPRs.  All lanes must be active. */
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned x)
+{
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false); /* row_ror:1 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false); /* row_ror:2 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false); /* row_ror:4 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false); /* row_ror:8 */
+	return (unsigned)__builtin_amdgcn_readlane((int)x, 0) + (unsigned)__builtin_amdgcn_readlane((int)x, 16) +
+	       (unsigned)__builtin_amdgcn_readlane((int)x, 32) + (unsigned)__builtin_amdgcn_readlane((int)x, 48);
+}
+
+/*
+ * k_zq_pipe: k_zq_spec with the two halves of an individual's work on different waves, so that they overlap.
+ * Every workgroup has DW draw waves (one locus per lane) and ONE control wave:
+ *   draw waves:   pick the Z of individual i (a candidate drawn earlier, or the plain path), ballot-count, publish
+ *                 the wave's counts (tagged words), store Z, then draw the candidates of individual i+1;
+ *   control wave: collect everybody's counts of individual i (packed 16-bit fields add without carries: a total
+ *                 stays below 2 Lp < 65536), run the Dirichlet (dirichlet_wave), hand the next start position to
+ *                 the draw waves through LDS.
+ * One workgroup barrier per individual joins them: the candidates of i+1 (the longest stretch of k_zq_spec's
+ * critical path) now run under the exchange and the Dirichlet of i.  Same Z, same counts, same consumption as
+ * k_zq_spec / k_zq_coop in every case.  Granule layout: gran[slot][w * NP + publisher], NP = G * DW waves.
+ */
+#ifndef ISG_PIPE_DW
+#define ISG_PIPE_DW 3
+#endif
+#define ISG_PIPE_RMAX 6
+#ifdef ISG_STAMPS
+#define STAMPC(i, k) do { if (threadIdx.x == 64 * DW && blockIdx.x == 0 && (i) < 4096) g_stamps[(i) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMPC(i, k) do { } while (0)
+#endif
+/* granules of k_zq_pipe: every publishing wave has a line of its own, 4352 bytes from the next one (4 KiB + 256 B:
+ * consecutive publishers fall on different HBM stacks AND channels).  With the granules packed into a dozen
+ * adjacent lines, every control wave polled the same memory channel and a poll's round trip was the queue there. */
+#define ISG_PIPE_STRIDE 544 /* 8-byte words */
+__device__ __forceinline__ unsigned long long *pipe_gran(unsigned long long *pg, int slot, int NP, int p, int w)
+{
+	return pg + ((size_t)slot * NP + p) * ISG_PIPE_STRIDE + w;
+}
+template <int KMAX, int DW>
+__global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh base, double alpha, CoopBuf *cb, unsigned long long *pg, uint64_t *pos_out, int xcd_pack)
+{
+	constexpr int BLOCK = 64 * (DW + 1), C = ISG_SPEC_C, LW = 64 * DW;
+	static_assert(KMAX <= 8 && C <= 8, "pre-filter rows in registers; candidates packed 4 bits each");
+	__shared__ ZqShared sh;
+	__shared__ unsigned long long off_sh[2];
+	__shared__ unsigned same_xcd;
+	if (xcd_pack && (blockIdx.x & 7)) return; /* every 8th block works: one XCD under round-robin placement */
+	const int t = threadIdx.x, g = xcd_pack ? blockIdx.x >> 3 : blockIdx.x, G = xcd_pack ? gridDim.x >> 3 : gridDim.x, K = d.K, lane = (int)lane_id();
+	const bool ctrl = (t >= LW);
+	{
+		const uint16_t *src = (const uint16_t *)d.tab;
+		uint16_t *dst = (uint16_t *)&sh.tab;
+		for (int k = t; k < (int)(sizeof(isg_wh_tables) / 2); k += BLOCK) dst[k] = src[k];
+		if (t < 3 * ISG_KCAP) {
+			(&sh.hist3[0][0])[t] = 0;
+			(&sh.ghist3[0][0])[t] = 0;
+		}
+		if (t < 2) off_sh[t] = 0;
+	}
+	__syncthreads();
+	/* all workgroups on one XCD (checked through the hardware register): the counts are handed over in its L2 */
+	const bool local = xcd_pack && coop_same_xcd(cb, g, G, &same_xcd);
+	const isg_wh cur = isg_wh_jump(&sh.tab, base, 0);
+	const int W = (K + 2) / 3, NP = G * DW;
+	const size_t rowb = (size_t)d.Lp * 2;
+	if (ctrl) {
+		/* ------------------------------- control wave ------------------------------- */
+		const bool writer = (g == 0);
+		unsigned long long off = 0;
+		int nvv = d.nvalid[min(lane, d.N - 1)], nvn = d.nvalid[min(64 + lane, d.N - 1)];
+		for (int i = 0; i < d.N; i++) {
+			if (i && !(i & 63)) {
+				nvv = nvn;
+				nvn = d.nvalid[min(i + 64 + lane, d.N - 1)];
+			}
+			const int nvalid = __builtin_amdgcn_readlane(nvv, i & 63);
+			const unsigned tag = (unsigned)(i % 65535) + 1u;
+			const int slot = i & (ISG_COOP_RING - 1);
+			const unsigned long long offi = off, dpos = offi + 2ull * (unsigned)nvalid;
+			const bool covered = dpos + 1024ull <= d.tape_len;
+			STAMPC(i, 4);
+			/* this lane's attempt of the Dirichlet (gamma m at offset m + dd, as dirichlet_wave lays them out): its two
+			 * uniforms are fetched now, under the exchange (the draw waves touched these lines an individual ago) */
+			double ppu0 = 0.0, ppu1 = 0.0;
+			if (covered) {
+				const int D = 64 / K, m = (lane < K * D) ? lane / D : K - 1, dd = lane - m * D;
+				ppu0 = d.tape[dpos + 2 * (m + dd)]; /* (a shape of exactly 1 makes the position odd: no 16-byte load) */
+				ppu1 = d.tape[dpos + 2 * (m + dd) + 1];
+			}
+			/* everybody's counts: the probes of all missing granules go out together; every spin is bounded and watches
+			 * the common abort word */
+			unsigned long long v[3][ISG_PIPE_RMAX];
+#pragma unroll
+			for (int w = 0; w < 3; w++)
+#pragma unroll
+				for (int r = 0; r < ISG_PIPE_RMAX; r++) {
+					const int p = r * 64 + lane;
+					v[w][r] = (w < W && r * 64 < NP && p < NP) ? 0ull : ((unsigned long long)tag << 48);
+				}
+			for (unsigned spin = 0;; spin++) {
+#pragma unroll
+				for (int w = 0; w < 3; w++)
+#pragma unroll
+					for (int r = 0; r < ISG_PIPE_RMAX; r++) {
+						const int p = r * 64 + lane;
+						if (w < W && r * 64 < NP && p < NP && (unsigned)(v[w][r] >> 48) != tag) v[w][r] = ld_agent(pipe_gran(pg, slot, NP, p, w));
+					}
+				bool miss = false;
+#pragma unroll
+				for (int w = 0; w < 3; w++)
+#pragma unroll
+					for (int r = 0; r < ISG_PIPE_RMAX; r++)
+						miss |= ((unsigned)(v[w][r] >> 48) != tag);
+				if (!__ballot(miss)) break;
+				if ((spin & 1023u) == 1023u) {
+					if (__hip_atomic_load(&cb->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+					if (spin > (1u << 22)) {
+						__hip_atomic_store(&cb->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						break;
+					}
+				}
+			}
+			unsigned lo[3] = {0u, 0u, 0u}, hi[3] = {0u, 0u, 0u};
+#pragma unroll
+			for (int w = 0; w < 3; w++)
+#pragma unroll
+				for (int r = 0; r < ISG_PIPE_RMAX; r++)
+					if (w < W && r * 64 < NP) {
+						lo[w] += (unsigned)v[w][r];
+						hi[w] += (unsigned)(v[w][r] >> 32) & 0xffffu;
+					}
+			unsigned cnt = 0;
+#pragma unroll
+			for (int w = 0; w < 3; w++)
+				if (w < W) {
+					const unsigned Ls = wave_sum_u32(lo[w]), Hs = wave_sum_u32(hi[w]);
+					cnt = (lane == 3 * w) ? (Ls & 0xffffu) : (lane == 3 * w + 1) ? (Ls >> 16) : (lane == 3 * w + 2) ? Hs : cnt;
+				}
+			if (lane < K) sh.ghist3[0][lane] = (int)cnt;
+			STAMPC(i, 3);
+			const unsigned used = 2u * (unsigned)nvalid +
+				dirichlet_wave<KMAX>(d, sh, i, cur, dpos, alpha, 0, covered ? d.tape + dpos : nullptr, writer, true, ppu0, ppu1);
+			off += used;
+			if (lane == 0) off_sh[(i + 1) & 1] = off;
+			STAMPC(i, 5);
+			lds_barrier();
+		}
+		if (g == 0 && lane == 0) *pos_out = off;
+		return;
+	}
+	/* --------------------------------- draw waves --------------------------------- */
+	const int j = g * LW + t; /* this lane's locus */
+	const int pub = g * DW + (t >> 6);
+	struct Loc {
+		unsigned a0, a1, rw;
+		float F0[KMAX], F1[KMAX];
+		double qv;
+		int nvv;
+	};
+	Loc cl, nl, ml;
+	auto fetch_geno = [&](int ni, Loc &L) {
+		L.a0 = L.a1 = 0xff;
+		L.rw = 0;
+		L.nvv = 0;
+		L.qv = 0.0;
+		if (ni < d.N) {
+			L.nvv = d.nvalid[min(ni + lane, d.N - 1)];
+			if (lane < K) L.qv = d.qq[(size_t)ni * K + lane];
+			if (j < d.Lp) {
+				const unsigned short gg = *(const unsigned short *)(d.geno + (size_t)ni * rowb + (size_t)j * 2);
+				L.a0 = gg & 0xff;
+				L.a1 = gg >> 8;
+				L.rw = d.rankwave[(size_t)ni * d.nwv + (j >> 6)];
+			}
+		}
+	};
+	auto fetch_rows = [&](Loc &L) {
+#pragma unroll
+		for (int m = 0; m < KMAX; m++) L.F0[m] = L.F1[m] = 0.f;
+		if (L.a0 != 0xff) {
+			const float *P0 = d.freqf + ((size_t)j * d.Amax + L.a0) * d.KPF, *P1 = d.freqf + ((size_t)j * d.Amax + L.a1) * d.KPF;
+#pragma unroll
+			for (int m = 0; m < KMAX; m += 4) {
+				if (m < K) {
+					const float4 f0 = *(const float4 *)(P0 + m), f1 = *(const float4 *)(P1 + m);
+					L.F0[m] = f0.x; L.F1[m] = f1.x;
+					if (m + 1 < KMAX) { L.F0[m + 1] = f0.y; L.F1[m + 1] = f1.y; }
+					if (m + 2 < KMAX) { L.F0[m + 2] = f0.z; L.F1[m + 2] = f1.z; }
+					if (m + 3 < KMAX) { L.F0[m + 3] = f0.w; L.F1[m + 3] = f1.w; }
+				}
+			}
+		}
+	};
+	fetch_geno(0, cl);
+	fetch_rows(cl);
+	fetch_geno(1, nl);
+	ml = nl;
+	double touch = 0.0;
+	unsigned cz0 = 0, cz1 = 0, camb = 0;
+	unsigned long long cbase = 0;
+	bool cvalid = false;
+	for (int i = 0; i < d.N; i++) {
+		const unsigned tag = (unsigned)(i % 65535) + 1u;
+		const int slot = i & (ISG_COOP_RING - 1);
+		const unsigned long long offi = off_sh[i & 1]; /* written by the control wave before the barrier that ended i - 1 */
+		const int nvalid = __builtin_amdgcn_readfirstlane(cl.nvv), nnvalid = __builtin_amdgcn_readfirstlane(nl.nvv);
+		const bool covered = offi + 2ull * (unsigned)nvalid + 1024ull <= d.tape_len;
+		const bool valid = (cl.a0 != 0xff);
+		const unsigned rank = cl.rw + (unsigned)__popcll(__ballot(valid) & ((1ull << lane) - 1ull));
+		STAMP(i, 0);
+		/* ---- this individual's Z: a candidate drawn earlier, or the plain path ---- */
+		const unsigned long long dc = offi - cbase;
+		const bool hit = cvalid && offi >= cbase && !(dc & 1ull) && dc < 2ull * C;
+		int z0 = 0xff, z1 = 0xff;
+		bool amb0 = false, amb1 = false;
+		if (hit) {
+			const unsigned c = (unsigned)(dc >> 1);
+			if (valid) {
+				z0 = (int)((cz0 >> (4 * c)) & 0xfu);
+				z1 = (int)((cz1 >> (4 * c)) & 0xfu);
+				amb0 = (camb >> c) & 1u;
+				amb1 = (camb >> (8 + c)) & 1u;
+			}
+		} else if (valid && covered) {
+			float qf[KMAX];
+#pragma unroll
+			for (int m = 0; m < KMAX; m++) qf[m] = (m < K) ? (float)readlane_f64(cl.qv, m) : 0.f;
+			const double x0 = d.tape[offi + 2ull * rank], x1 = d.tape[offi + 2ull * rank + 1];
+			z0 = bucket_f32<KMAX>((float)x0, cl.F0, qf, K, &amb0);
+			z1 = bucket_f32<KMAX>((float)x1, cl.F1, qf, K, &amb1);
+		}
+		if (__ballot(valid && covered && (amb0 || amb1))) { /* rare: the draw in double */
+			double cum[KMAX], q[KMAX];
+#pragma unroll
+			for (int m = 0; m < KMAX; m++) q[m] = (m < K) ? readlane_f64(cl.qv, m) : 0.0;
+			if (valid && covered && amb0) {
+				const double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + cl.a0) * d.KP, q, cum, K);
+				z0 = bucket_fast<KMAX>(d.tape[offi + 2ull * rank], cum, tot, K);
+			}
+			if (valid && covered && amb1) {
+				const double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + cl.a1) * d.KP, q, cum, K);
+				z1 = bucket_fast<KMAX>(d.tape[offi + 2ull * rank + 1], cum, tot, K);
+			}
+		}
+		if (!covered) { z0 = z1 = 0xff; }
+		int wcnt[KMAX];
+#pragma unroll
+		for (int m = 0; m < KMAX; m++) wcnt[m] = (m < K) ? __popcll(__ballot(z0 == m)) + __popcll(__ballot(z1 == m)) : 0;
+		STAMP(i, 1);
+		/* ---- counts leave ---- */
+		{
+			unsigned long long v = (unsigned long long)tag << 48;
+#pragma unroll
+			for (int m = 0; m < KMAX; m++)
+				if (m < K && lane == m / 3) v |= (unsigned long long)(wcnt[m] & 0xffff) << (16 * (m % 3));
+			if (lane < W) { if (local) st_xcd(pipe_gran(pg, slot, NP, pub, lane), v); else st_agent(pipe_gran(pg, slot, NP, pub, lane), v); }
+		}
+		STAMP(i, 2);
+		if (j < d.Lp) *(unsigned short *)(d.z + (size_t)i * rowb + (size_t)j * 2) = (unsigned short)(z0 | (z1 << 8));
+		if (!covered && t == 0) cb->overflow_flag = 1;
+		/* ---- the next individual's candidates (under the Dirichlet of this one) ---- */
+		const unsigned long long nbase = offi + 2ull * (unsigned)nvalid + 2ull * (unsigned)K; /* every gamma: >= one attempt of two uniforms */
+		const bool nvalidc = (i + 1 < d.N) && (nbase + 2ull * (C - 1) + 2ull * (unsigned)nnvalid + 1024ull <= d.tape_len);
+		const bool nvalidl = (nl.a0 != 0xff);
+		const unsigned nrank = nl.rw + (unsigned)__popcll(__ballot(nvalidl) & ((1ull << lane) - 1ull));
+		double xs[2 * C];
+#pragma unroll
+		for (int k = 0; k < 2 * C; k++) xs[k] = 0.5;
+		if (nvalidc && nvalidl) {
+			const double *tp = d.tape + nbase + 2ull * nrank;
+#pragma unroll
+			for (int k = 0; k < 2 * C; k++) xs[k] = tp[k];
+		}
+		fetch_rows(nl);
+		fetch_geno(i + 2, ml);
+		/* the next Dirichlet's stretch of the tape (its start is known up to this Dirichlet's rejected attempts: 160
+		 * uniforms cover that), so that the control wave finds it in L2 */
+		if (touch == -1.0) cb->overflow_flag = 2;
+		if (t < 10 && nvalidc) touch = d.tape[nbase + 2ull * (unsigned)nnvalid + 16u * (unsigned)t];
+		cbase = nbase;
+		cvalid = nvalidc;
+		cz0 = cz1 = camb = 0;
+		if (nvalidc && nvalidl) {
+			float qf[KMAX], cum0[KMAX], cum1[KMAX];
+#pragma unroll
+			for (int m = 0; m < KMAX; m++) qf[m] = (m < K) ? (float)readlane_f64(nl.qv, m) : 0.f;
+			const float run0 = prefix_f32<KMAX>(nl.F0, qf, K, cum0), run1 = prefix_f32<KMAX>(nl.F1, qf, K, cum1);
+#pragma unroll
+			for (int c = 0; c < C; c++) {
+				bool a0, a1;
+				const int b0 = bucket_from_cum<KMAX>((float)xs[2 * c], cum0, run0, K, &a0);
+				const int b1 = bucket_from_cum<KMAX>((float)xs[2 * c + 1], cum1, run1, K, &a1);
+				cz0 |= (unsigned)b0 << (4 * c);
+				cz1 |= (unsigned)b1 << (4 * c);
+				camb |= (a0 ? 1u : 0u) << c;
+				camb |= (a1 ? 1u : 0u) << (8 + c);
+			}
+		}
+		STAMP(i, 6);
+		cl = nl;
+		nl = ml;
+		lds_barrier();
+	}
 }
 
 /* the uniforms at positions [0, n) after `base`, in stream order (8 per lane: one skip-ahead, then stepping) */
@@ -2321,6 +2641,10 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 		c->spec = (e && atoi(e) == 0) ? 0 : 1;
 		e = getenv("INSTRUCT_ZQ_XCD"); /* experimental, off by default: measured gain at config 3 is within noise */
 		c->xcd = (e && atoi(e) == 1) ? 1 : 0;
+		e = getenv("INSTRUCT_ZQ_PIPE");
+		c->pipe = (e && atoi(e) == 0) ? 0 : 1;
+		e = getenv("INSTRUCT_ZQ_PIPE_XCD");
+		c->pipe_xcd = (e && atoi(e) == 0) ? 0 : 1;
 	}
 	DALLOC(d.cnt, int, (size_t)Lp * Amax * K);
 	DALLOC(d.qq, double, (size_t)N * K);
@@ -2388,7 +2712,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	}
 	inbreed_free(c);
 	DevView &d = c->d;
-	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(d.lftab); (void)hipFree(d.lltab); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(d.cnt);
+	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(d.lftab); (void)hipFree(d.lltab); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(c->d_pipe); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
 	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S); (void)hipFree(c->d_Fprop); (void)hipFree(c->d_state); (void)hipFree(c->d_ratios); (void)hipFree(c->d_total);
 	prof_collect(c);
@@ -2681,13 +3005,38 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 		int G = (c->d.Lp + 255) / 256;
 		if (G > ISG_COOP_GMAX) G = ISG_COOP_GMAX;
 		CoopBuf *cb = (CoopBuf *)c->d_coop;
-		prof_begin(c);
-#define COOP_LAUNCH(KM) hipLaunchKernelGGL((k_zq_coop<KM>), dim3(pack ? 8 * G : G), dim3(256), 0, c->stream, c->d, base, init_flag, c->alpha, cb, c->d_pos, pack)
 		/* few enough workgroups for one XCD (32 CUs): start 8 G blocks, every 8th works (see coop_same_xcd) */
 		const int pack = (G <= 32 && c->xcd) ? 1 : 0;
-#define SPEC_LAUNCH(KM) hipLaunchKernelGGL((k_zq_spec<KM>), dim3(pack ? 8 * G : G), dim3(256), 0, c->stream, c->d, base, c->alpha, cb, c->d_pos, pack)
 		const bool spec = !init_flag && K <= 8 && G * 256 >= c->d.Lp && c->spec;
-		if (spec) {
+		/* draw waves + control wave: single pass over the loci, packed 16-bit totals, every workgroup resident */
+		const int GP = (c->d.Lp + 64 * ISG_PIPE_DW - 1) / (64 * ISG_PIPE_DW);
+		const bool pipe = spec && c->pipe && !pack && 2 * c->d.Lp < 65536 && GP * ISG_PIPE_DW <= 64 * ISG_PIPE_RMAX && GP <= 192;
+		const int ppack = (GP <= 32 && c->pipe_xcd) ? 1 : 0;
+		if (pipe) {
+			const size_t need_words = (size_t)ISG_COOP_RING * GP * ISG_PIPE_DW * ISG_PIPE_STRIDE;
+			if (need_words > c->pipe_cap) {
+				if (c->d_pipe) HIPCHK(hipFree(c->d_pipe));
+				c->d_pipe = nullptr;
+				c->pipe_cap = 0;
+				HIPCHK(hipMalloc((void **)&c->d_pipe, need_words * sizeof(unsigned long long)));
+				c->pipe_cap = need_words;
+			}
+			HIPCHK(hipMemsetAsync(c->d_pipe, 0, need_words * sizeof(unsigned long long), c->stream));
+		}
+		prof_begin(c);
+#define COOP_LAUNCH(KM) hipLaunchKernelGGL((k_zq_coop<KM>), dim3(pack ? 8 * G : G), dim3(256), 0, c->stream, c->d, base, init_flag, c->alpha, cb, c->d_pos, pack)
+#define SPEC_LAUNCH(KM) hipLaunchKernelGGL((k_zq_spec<KM>), dim3(pack ? 8 * G : G), dim3(256), 0, c->stream, c->d, base, c->alpha, cb, c->d_pos, pack)
+#define PIPE_LAUNCH(KM) hipLaunchKernelGGL((k_zq_pipe<KM, ISG_PIPE_DW>), dim3(ppack ? 8 * GP : GP), dim3(64 * (ISG_PIPE_DW + 1)), 0, c->stream, c->d, base, c->alpha, cb, c->d_pipe, c->d_pos, ppack)
+		if (pipe) {
+			switch (K) {
+			case 1: case 2: PIPE_LAUNCH(2); break;
+			case 3: PIPE_LAUNCH(3); break;
+			case 4: PIPE_LAUNCH(4); break;
+			case 5: PIPE_LAUNCH(5); break;
+			case 6: PIPE_LAUNCH(6); break;
+			default: PIPE_LAUNCH(8); break;
+			}
+		} else if (spec) {
 			switch (K) {
 			case 1: case 2: SPEC_LAUNCH(2); break;
 			case 3: SPEC_LAUNCH(3); break;
@@ -2711,7 +3060,7 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 			else COOP_LAUNCH(32);
 		}
 #undef COOP_LAUNCH
-		prof_end(c, spec ? "k_zq_spec" : "k_zq_coop");
+		prof_end(c, pipe ? "k_zq_pipe" : spec ? "k_zq_spec" : "k_zq_coop");
 		HIPCHK(hipGetLastError());
 		uint64_t used = 0;
 		unsigned flags[2] = {0, 0};

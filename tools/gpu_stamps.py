@@ -5,7 +5,12 @@ sys.path.insert(0, ROOT)
 import numpy as np
 diag = os.path.join(ROOT, "gpurun_out", "libdiag.so")
 extra = [a for a in sys.argv[3:] if a.startswith("-D")]
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DISG_STAMPS"] + extra + [
+pre = os.path.join(ROOT, "tools", "_diag", "libdiag.so")   # built in the container with the same flags (travels with the snapshot)
+pre = os.environ.get("ISG_DIAG_LIB", pre)
+if os.path.exists(pre) and not extra:
+    diag = pre
+else:
+  subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DISG_STAMPS"] + extra + [
                        "-o", diag, os.path.join(ROOT, "instruct_amd/csrc/isg_hip.hip")])
 from instruct_amd import capi, synth
 capi.LIB_PATH = diag
@@ -40,6 +45,16 @@ elif os.environ.get("INSTRUCT_ZQ_COOP", "1") != "0":
     if os.environ.get("INSTRUCT_ZQ_SPEC", "1") != "0":
         order = [0, 1, 2, 6, 3, 5]
         names = ["top->z picked+stored", "->published", "->candidates drawn", "->gathered", "->Dirichlet (per wave)"]
+        if os.environ.get("INSTRUCT_ZQ_PIPE", "1") != "0":
+            # draw waves: 0 top, 1 picked, 2 published, 6 candidates; control wave: 4 top, 3 gathered, 5 Dirichlet done
+            order = [0, 1, 2, 6]
+            names = ["draw: top->z picked", "->published+stored", "->candidates drawn"]
+            dc = np.diff(s[:, [4, 3, 5]], axis=1)
+            for n, col in zip(["ctrl: top->gathered", "->Dirichlet"], dc.T):
+                q = np.percentile(col, [5, 25, 50, 75, 95, 99])
+                print(f"{n:22s} {col.mean():9.0f} ticks   pct 5/25/50/75/95/99: " + " ".join("%6.0f" % x for x in q))
+            print("ctrl top - draw top (same individual):", (s[:, 4] - s[:, 0]).mean(), " draw candidates done -> next top:", (s[1:, 0] - s[:-1, 6]).mean(),
+                  " ctrl Dirichlet done -> next ctrl top:", (s[1:, 4] - s[:-1, 5]).mean())
     if "-DISG_EXP_XWAIT" in extra:
         order = [0, 2, 3, 6, 7, 1, 4, 5]
         names = ["top->x issued", "->x arrived", "->prefetch issued", "->buckets", "->counts+store", "->(publish+gather+attempts)", "->walk"]

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "gpurun_out")
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
-SHORT = [("k_zq_spec", "k_zq_spec"), ("k_zq_coop", "k_zq_coop"), ("k4_zq_coop", "k4_zq_coop"), ("k_zq<256", "k_zq_keyed"), ("k_zq<512", "k_zq_chain"),
+SHORT = [("k_zq_pipe", "k_zq_pipe"), ("k_zq_spec", "k_zq_spec"), ("k_zq_coop", "k_zq_coop"), ("k4_zq_coop", "k4_zq_coop"), ("k_zq<256", "k_zq_keyed"), ("k_zq<512", "k_zq_chain"),
          ("k_loglik<256, true>", "k_loglik_pair"), ("k_loglik<256, false>", "k_loglik_lkh"),
          ("k_loglik_tab<256, true>", "k_loglik_pair"), ("k_loglik_tab<256, false>", "k_loglik_lkh"), ("k4_zq<256", "k4_zq_keyed")]
 
