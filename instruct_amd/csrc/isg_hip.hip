@@ -1970,17 +1970,34 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned x)
 	       (unsigned)__builtin_amdgcn_readlane((int)x, 32) + (unsigned)__builtin_amdgcn_readlane((int)x, 48);
 }
 
+/* the same sum in every lane: rotations inside the rows of 16 lanes, then the rows through two cross-lane exchanges */
+__device__ __forceinline__ unsigned wave_allsum_u32(unsigned x)
+{
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false); /* row_ror:1 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false); /* row_ror:2 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false); /* row_ror:4 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false); /* row_ror:8 */
+	x += (unsigned)__shfl_xor((int)x, 16, 64);
+	x += (unsigned)__shfl_xor((int)x, 32, 64);
+	return x;
+}
+
 /*
- * k_zq_pipe: k_zq_spec with the two halves of an individual's work on different waves, so that they overlap.
- * Every workgroup has DW draw waves (one locus per lane) and ONE control wave:
- *   draw waves:   pick the Z of individual i (a candidate drawn earlier, or the plain path), ballot-count, publish
- *                 the wave's counts (tagged words), store Z, then draw the candidates of individual i+1;
- *   control wave: collect everybody's counts of individual i (packed 16-bit fields add without carries: a total
- *                 stays below 2 Lp < 65536), run the Dirichlet (dirichlet_wave), hand the next start position to
- *                 the draw waves through LDS.
- * One workgroup barrier per individual joins them: the candidates of i+1 (the longest stretch of k_zq_spec's
- * critical path) now run under the exchange and the Dirichlet of i.  Same Z, same counts, same consumption as
- * k_zq_spec / k_zq_coop in every case.  Granule layout: gran[slot][w * NP + publisher], NP = G * DW waves.
+ * k_zq_pipe: the replay update_ZQ chain with the exchange of an individual's counts taken off the critical path.
+ * Every workgroup has DW draw waves (one locus per lane) and ONE control wave; nothing but LDS words joins them.
+ *   draw waves:   individual i starts where the control wave says (LDS).  Its Z is the candidate drawn earlier for
+ *                 that start position (95 %), or the plain path.  Then the C candidates of individual i+1 are drawn
+ *                 (start = end of i's draws + 2 K + 2 c, c = rejected attempts of i's Dirichlet), the few draws the
+ *                 single precision filter could not decide are redone in double, and the wave's counts of EVERY
+ *                 candidate leave as tagged words -- before anybody knows which candidate it will be.
+ *   control wave: knows c when its Dirichlet of i-1 is done; the counts of individual i for that candidate were
+ *                 published while that Dirichlet and the exchange before it ran, so they have arrived or are about
+ *                 to; it sums them (packed 16-bit fields add without carries: a total stays below 2 Lp < 65536), runs
+ *                 the Dirichlet of i (dirichlet_wave) and posts the next start position.
+ * A start position no candidate was drawn for (5 %: c >= C, a shape of exactly 1, the first individual) takes the
+ * plain path: the draw waves draw Z then, publish the counts in a set of their own, and the control wave waits for
+ * those.  Same Z, same counts, same consumption as k_zq_spec / k_zq_coop in every case.
+ * Granules: pipe_gran(slot of the individual, publishing wave, set * W + w); set = candidate, or C for the plain path.
  */
 #ifndef ISG_PIPE_DW
 #define ISG_PIPE_DW 3
@@ -1991,9 +2008,8 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned x)
 #else
 #define STAMPC(i, k) do { } while (0)
 #endif
-/* granules of k_zq_pipe: every publishing wave has a line of its own, 4352 bytes from the next one (4 KiB + 256 B:
- * consecutive publishers fall on different HBM stacks AND channels).  With the granules packed into a dozen
- * adjacent lines, every control wave polled the same memory channel and a poll's round trip was the queue there. */
+/* granules of k_zq_pipe: every publishing wave has lines of its own, 4352 bytes from the next wave's (4 KiB + 256 B:
+ * consecutive publishers fall on different HBM stacks AND channels). */
 #define ISG_PIPE_STRIDE 544 /* 8-byte words */
 __device__ __forceinline__ unsigned long long *pipe_gran(unsigned long long *pg, int slot, int NP, int p, int w)
 {
@@ -2005,7 +2021,8 @@ __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh bas
 	constexpr int BLOCK = 64 * (DW + 1), C = ISG_SPEC_C, LW = 64 * DW;
 	static_assert(KMAX <= 8 && C <= 8, "pre-filter rows in registers; candidates packed 4 bits each");
 	__shared__ ZqShared sh;
-	__shared__ unsigned long long off_sh[2];
+	__shared__ unsigned long long off_sh[4]; /* start position of individual i in off_sh[i & 3] ... */
+	__shared__ unsigned seq_sh;              /* ... valid once seq_sh >= i */
 	__shared__ unsigned same_xcd;
 	if (xcd_pack && (blockIdx.x & 7)) return; /* every 8th block works: one XCD under round-robin placement */
 	const int t = threadIdx.x, g = xcd_pack ? blockIdx.x >> 3 : blockIdx.x, G = xcd_pack ? gridDim.x >> 3 : gridDim.x, K = d.K, lane = (int)lane_id();
@@ -2018,7 +2035,8 @@ __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh bas
 			(&sh.hist3[0][0])[t] = 0;
 			(&sh.ghist3[0][0])[t] = 0;
 		}
-		if (t < 2) off_sh[t] = 0;
+		if (t < 4) off_sh[t] = 0;
+		if (t == 4) seq_sh = 0;
 	}
 	__syncthreads();
 	/* all workgroups on one XCD (checked through the hardware register): the counts are handed over in its L2 */
@@ -2029,7 +2047,8 @@ __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh bas
 	if (ctrl) {
 		/* ------------------------------- control wave ------------------------------- */
 		const bool writer = (g == 0);
-		unsigned long long off = 0;
+		unsigned long long off = 0, pcbase = 0;
+		bool pcvalid = false;
 		int nvv = d.nvalid[min(lane, d.N - 1)], nvn = d.nvalid[min(64 + lane, d.N - 1)];
 		for (int i = 0; i < d.N; i++) {
 			if (i && !(i & 63)) {
@@ -2037,10 +2056,15 @@ __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh bas
 				nvn = d.nvalid[min(i + 64 + lane, d.N - 1)];
 			}
 			const int nvalid = __builtin_amdgcn_readlane(nvv, i & 63);
+			const int nvnext = ((i + 1) & 63) ? __builtin_amdgcn_readlane(nvv, (i + 1) & 63) : __builtin_amdgcn_readlane(nvn, 0);
 			const unsigned tag = (unsigned)(i % 65535) + 1u;
 			const int slot = i & (ISG_COOP_RING - 1);
 			const unsigned long long offi = off, dpos = offi + 2ull * (unsigned)nvalid;
 			const bool covered = dpos + 1024ull <= d.tape_len;
+			/* which set of counts: the draw waves decide the same way from the same numbers */
+			const unsigned long long dc = offi - pcbase;
+			const bool hit = pcvalid && offi >= pcbase && !(dc & 1ull) && dc < 2ull * C;
+			const int set = hit ? (int)(dc >> 1) : C;
 			STAMPC(i, 4);
 			/* this lane's attempt of the Dirichlet (gamma m at offset m + dd, as dirichlet_wave lays them out): its two
 			 * uniforms are fetched now, under the exchange (the draw waves touched these lines an individual ago) */
@@ -2066,7 +2090,7 @@ __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh bas
 #pragma unroll
 					for (int r = 0; r < ISG_PIPE_RMAX; r++) {
 						const int p = r * 64 + lane;
-						if (w < W && r * 64 < NP && p < NP && (unsigned)(v[w][r] >> 48) != tag) v[w][r] = ld_agent(pipe_gran(pg, slot, NP, p, w));
+						if (w < W && r * 64 < NP && p < NP && (unsigned)(v[w][r] >> 48) != tag) v[w][r] = ld_agent(pipe_gran(pg, slot, NP, p, set * W + w));
 					}
 				bool miss = false;
 #pragma unroll
@@ -2104,16 +2128,25 @@ __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh bas
 			const unsigned used = 2u * (unsigned)nvalid +
 				dirichlet_wave<KMAX>(d, sh, i, cur, dpos, alpha, 0, covered ? d.tape + dpos : nullptr, writer, true, ppu0, ppu1);
 			off += used;
-			if (lane == 0) off_sh[(i + 1) & 1] = off;
+			if (lane == 0) {
+				off_sh[(i + 1) & 3] = off;
+				__hip_atomic_store(&seq_sh, (unsigned)(i + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+			/* the candidates the draw waves are drawing for individual i + 1 */
+			pcbase = dpos + 2ull * (unsigned)K;
+			pcvalid = (i + 1 < d.N) && (pcbase + 2ull * (C - 1) + 2ull * (unsigned)nvnext + 1024ull <= d.tape_len);
 			STAMPC(i, 5);
-			lds_barrier();
 		}
 		if (g == 0 && lane == 0) *pos_out = off;
+#ifdef ISG_STAMPS
+		if (g == 0 && lane == 0) g_stamps[4095 * 8 + 4] = (local ? 1ull : 0ull) | ((unsigned long long)xcc_id() << 8) | ((unsigned long long)G << 16);
+#endif
 		return;
 	}
 	/* --------------------------------- draw waves --------------------------------- */
 	const int j = g * LW + t; /* this lane's locus */
 	const int pub = g * DW + (t >> 6);
+	const int myc = lane / W, myw = lane % W; /* the candidate and the word this lane publishes */
 	struct Loc {
 		unsigned a0, a1, rw;
 		float F0[KMAX], F1[KMAX];
@@ -2158,70 +2191,70 @@ __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh bas
 	fetch_rows(cl);
 	fetch_geno(1, nl);
 	ml = nl;
-	double touch = 0.0;
-	unsigned cz0 = 0, cz1 = 0, camb = 0;
+	unsigned cz0 = 0, cz1 = 0;
 	unsigned long long cbase = 0;
 	bool cvalid = false;
+	double touch = 0.0;
 	for (int i = 0; i < d.N; i++) {
-		const unsigned tag = (unsigned)(i % 65535) + 1u;
-		const int slot = i & (ISG_COOP_RING - 1);
-		const unsigned long long offi = off_sh[i & 1]; /* written by the control wave before the barrier that ended i - 1 */
+		const unsigned tag = (unsigned)(i % 65535) + 1u, ntag = (unsigned)((i + 1) % 65535) + 1u;
+		const int slot = i & (ISG_COOP_RING - 1), nslot = (i + 1) & (ISG_COOP_RING - 1);
+		/* the start position, posted by the control wave when its Dirichlet of individual i - 1 was done */
+		while (__hip_atomic_load(&seq_sh, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)i) __builtin_amdgcn_s_sleep(1);
+		const unsigned long long offi = off_sh[i & 3];
 		const int nvalid = __builtin_amdgcn_readfirstlane(cl.nvv), nnvalid = __builtin_amdgcn_readfirstlane(nl.nvv);
 		const bool covered = offi + 2ull * (unsigned)nvalid + 1024ull <= d.tape_len;
 		const bool valid = (cl.a0 != 0xff);
-		const unsigned rank = cl.rw + (unsigned)__popcll(__ballot(valid) & ((1ull << lane) - 1ull));
 		STAMP(i, 0);
-		/* ---- this individual's Z: a candidate drawn earlier, or the plain path ---- */
+		/* ---- this individual's Z: a candidate drawn earlier (its counts left then), or the plain path ---- */
 		const unsigned long long dc = offi - cbase;
 		const bool hit = cvalid && offi >= cbase && !(dc & 1ull) && dc < 2ull * C;
 		int z0 = 0xff, z1 = 0xff;
-		bool amb0 = false, amb1 = false;
 		if (hit) {
 			const unsigned c = (unsigned)(dc >> 1);
 			if (valid) {
 				z0 = (int)((cz0 >> (4 * c)) & 0xfu);
 				z1 = (int)((cz1 >> (4 * c)) & 0xfu);
-				amb0 = (camb >> c) & 1u;
-				amb1 = (camb >> (8 + c)) & 1u;
 			}
-		} else if (valid && covered) {
-			float qf[KMAX];
+		} else {
+			const unsigned rank = cl.rw + (unsigned)__popcll(__ballot(valid) & ((1ull << lane) - 1ull));
+			bool amb0 = false, amb1 = false;
+			if (valid && covered) {
+				float qf[KMAX];
 #pragma unroll
-			for (int m = 0; m < KMAX; m++) qf[m] = (m < K) ? (float)readlane_f64(cl.qv, m) : 0.f;
-			const double x0 = d.tape[offi + 2ull * rank], x1 = d.tape[offi + 2ull * rank + 1];
-			z0 = bucket_f32<KMAX>((float)x0, cl.F0, qf, K, &amb0);
-			z1 = bucket_f32<KMAX>((float)x1, cl.F1, qf, K, &amb1);
-		}
-		if (__ballot(valid && covered && (amb0 || amb1))) { /* rare: the draw in double */
-			double cum[KMAX], q[KMAX];
-#pragma unroll
-			for (int m = 0; m < KMAX; m++) q[m] = (m < K) ? readlane_f64(cl.qv, m) : 0.0;
-			if (valid && covered && amb0) {
-				const double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + cl.a0) * d.KP, q, cum, K);
-				z0 = bucket_fast<KMAX>(d.tape[offi + 2ull * rank], cum, tot, K);
+				for (int m = 0; m < KMAX; m++) qf[m] = (m < K) ? (float)readlane_f64(cl.qv, m) : 0.f;
+				const double x0 = d.tape[offi + 2ull * rank], x1 = d.tape[offi + 2ull * rank + 1];
+				z0 = bucket_f32<KMAX>((float)x0, cl.F0, qf, K, &amb0);
+				z1 = bucket_f32<KMAX>((float)x1, cl.F1, qf, K, &amb1);
 			}
-			if (valid && covered && amb1) {
-				const double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + cl.a1) * d.KP, q, cum, K);
-				z1 = bucket_fast<KMAX>(d.tape[offi + 2ull * rank + 1], cum, tot, K);
-			}
-		}
-		if (!covered) { z0 = z1 = 0xff; }
-		int wcnt[KMAX];
+			if (__ballot(valid && covered && (amb0 || amb1))) { /* rare: the draw in double */
+				double cum[KMAX], q[KMAX];
 #pragma unroll
-		for (int m = 0; m < KMAX; m++) wcnt[m] = (m < K) ? __popcll(__ballot(z0 == m)) + __popcll(__ballot(z1 == m)) : 0;
-		STAMP(i, 1);
-		/* ---- counts leave ---- */
-		{
+				for (int m = 0; m < KMAX; m++) q[m] = (m < K) ? readlane_f64(cl.qv, m) : 0.0;
+				if (valid && covered && amb0) {
+					const double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + cl.a0) * d.KP, q, cum, K);
+					z0 = bucket_fast<KMAX>(d.tape[offi + 2ull * rank], cum, tot, K);
+				}
+				if (valid && covered && amb1) {
+					const double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + cl.a1) * d.KP, q, cum, K);
+					z1 = bucket_fast<KMAX>(d.tape[offi + 2ull * rank + 1], cum, tot, K);
+				}
+			}
+			if (!covered) { z0 = z1 = 0xff; }
+			/* the plain path's counts: set C */
 			unsigned long long v = (unsigned long long)tag << 48;
 #pragma unroll
 			for (int m = 0; m < KMAX; m++)
-				if (m < K && lane == m / 3) v |= (unsigned long long)(wcnt[m] & 0xffff) << (16 * (m % 3));
-			if (lane < W) { if (local) st_xcd(pipe_gran(pg, slot, NP, pub, lane), v); else st_agent(pipe_gran(pg, slot, NP, pub, lane), v); }
+				if (m < K) {
+					const int wc = __popcll(__ballot(z0 == m)) + __popcll(__ballot(z1 == m));
+					if (lane == m / 3) v |= (unsigned long long)(wc & 0xffff) << (16 * (m % 3));
+				}
+			if (lane < W) { if (local) st_xcd(pipe_gran(pg, slot, NP, pub, C * W + lane), v); else st_agent(pipe_gran(pg, slot, NP, pub, C * W + lane), v); }
 		}
-		STAMP(i, 2);
+		STAMP(i, 1);
 		if (j < d.Lp) *(unsigned short *)(d.z + (size_t)i * rowb + (size_t)j * 2) = (unsigned short)(z0 | (z1 << 8));
 		if (!covered && t == 0) cb->overflow_flag = 1;
-		/* ---- the next individual's candidates (under the Dirichlet of this one) ---- */
+		STAMP(i, 2);
+		/* ---- the next individual's candidates ---- */
 		const unsigned long long nbase = offi + 2ull * (unsigned)nvalid + 2ull * (unsigned)K; /* every gamma: >= one attempt of two uniforms */
 		const bool nvalidc = (i + 1 < d.N) && (nbase + 2ull * (C - 1) + 2ull * (unsigned)nnvalid + 1024ull <= d.tape_len);
 		const bool nvalidl = (nl.a0 != 0xff);
@@ -2242,27 +2275,67 @@ __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh bas
 		if (t < 10 && nvalidc) touch = d.tape[nbase + 2ull * (unsigned)nnvalid + 16u * (unsigned)t];
 		cbase = nbase;
 		cvalid = nvalidc;
-		cz0 = cz1 = camb = 0;
-		if (nvalidc && nvalidl) {
-			float qf[KMAX], cum0[KMAX], cum1[KMAX];
+		cz0 = cz1 = 0;
+		if (nvalidc) { /* wave-uniform */
+			unsigned camb = 0;
+			if (nvalidl) {
+				float qf[KMAX], cum0[KMAX], cum1[KMAX];
 #pragma unroll
-			for (int m = 0; m < KMAX; m++) qf[m] = (m < K) ? (float)readlane_f64(nl.qv, m) : 0.f;
-			const float run0 = prefix_f32<KMAX>(nl.F0, qf, K, cum0), run1 = prefix_f32<KMAX>(nl.F1, qf, K, cum1);
+				for (int m = 0; m < KMAX; m++) qf[m] = (m < K) ? (float)readlane_f64(nl.qv, m) : 0.f;
+				const float run0 = prefix_f32<KMAX>(nl.F0, qf, K, cum0), run1 = prefix_f32<KMAX>(nl.F1, qf, K, cum1);
+#pragma unroll
+				for (int c = 0; c < C; c++) {
+					bool a0, a1;
+					const int b0 = bucket_from_cum<KMAX>((float)xs[2 * c], cum0, run0, K, &a0);
+					const int b1 = bucket_from_cum<KMAX>((float)xs[2 * c + 1], cum1, run1, K, &a1);
+					cz0 |= (unsigned)b0 << (4 * c);
+					cz1 |= (unsigned)b1 << (4 * c);
+					camb |= (a0 ? 1u : 0u) << c;
+					camb |= (a1 ? 1u : 0u) << (8 + c);
+				}
+			}
+			STAMP(i, 6);
+			if (__ballot(camb != 0u)) { /* rare (about 4 % of the waves): the draws the filter could not decide, in double */
+				double cum[KMAX], q[KMAX];
+#pragma unroll
+				for (int m = 0; m < KMAX; m++) q[m] = (m < K) ? readlane_f64(nl.qv, m) : 0.0;
+				if (camb & 0xffu) {
+					const double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + nl.a0) * d.KP, q, cum, K);
+#pragma unroll
+					for (int c = 0; c < C; c++)
+						if ((camb >> c) & 1u) cz0 = (cz0 & ~(0xfu << (4 * c))) | ((unsigned)bucket_fast<KMAX>(xs[2 * c], cum, tot, K) << (4 * c));
+				}
+				if (camb >> 8) {
+					const double tot = weights<KMAX>(d.freq + ((size_t)j * d.Amax + nl.a1) * d.KP, q, cum, K);
+#pragma unroll
+					for (int c = 0; c < C; c++)
+						if ((camb >> (8 + c)) & 1u) cz1 = (cz1 & ~(0xfu << (4 * c))) | ((unsigned)bucket_fast<KMAX>(xs[2 * c + 1], cum, tot, K) << (4 * c));
+				}
+			}
+			/* the wave's counts of every candidate: lane c * W + w carries word w of candidate c.  A lane's two draws as
+			 * 8-bit fields (one per cluster), summed over the wave with DPP adds (a field stays <= 128: no carries) --
+			 * 2 K ballots and scalar popcounts per candidate took 5 k cycles here */
+			unsigned mylo = 0, myhi = 0;
 #pragma unroll
 			for (int c = 0; c < C; c++) {
-				bool a0, a1;
-				const int b0 = bucket_from_cum<KMAX>((float)xs[2 * c], cum0, run0, K, &a0);
-				const int b1 = bucket_from_cum<KMAX>((float)xs[2 * c + 1], cum1, run1, K, &a1);
-				cz0 |= (unsigned)b0 << (4 * c);
-				cz1 |= (unsigned)b1 << (4 * c);
-				camb |= (a0 ? 1u : 0u) << c;
-				camb |= (a1 ? 1u : 0u) << (8 + c);
+				unsigned long long P = 0;
+				if (nvalidl) P = (1ull << (8 * ((cz0 >> (4 * c)) & 0xfu))) + (1ull << (8 * ((cz1 >> (4 * c)) & 0xfu)));
+				const unsigned plo = wave_allsum_u32((unsigned)P), phi = (KMAX > 4) ? wave_allsum_u32((unsigned)(P >> 32)) : 0u;
+				if (myc == c) {
+					mylo = plo;
+					myhi = phi;
+				}
 			}
+			const unsigned long long my = ((unsigned long long)myhi << 32) | mylo;
+			unsigned long long v = (unsigned long long)ntag << 48;
+#pragma unroll
+			for (int k = 0; k < 3; k++)
+				if (3 * myw + k < 8) v |= ((my >> (8 * (3 * myw + k))) & 0xffull) << (16 * k);
+			if (lane < C * W) { if (local) st_xcd(pipe_gran(pg, nslot, NP, pub, lane), v); else st_agent(pipe_gran(pg, nslot, NP, pub, lane), v); }
 		}
-		STAMP(i, 6);
+		STAMP(i, 7);
 		cl = nl;
 		nl = ml;
-		lds_barrier();
 	}
 }
 

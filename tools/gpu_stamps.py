@@ -33,6 +33,7 @@ else:
 h.iteration(); h.iteration()
 buf = np.zeros((4096, 8), dtype=np.uint64)
 h.lib.isg_diag_stamps(buf.ctypes.data_as(C.c_void_p))
+print("same-XCD hand-off: %d  (XCC %d, %d workgroups)" % (int(buf[4095, 4]) & 1, (int(buf[4095, 4]) >> 8) & 0xff, int(buf[4095, 4]) >> 16))
 s = buf[100:min(N, 4000)].astype(np.int64)
 if tetra:
     order = [0, 1, 2, 3, 4, 5]
@@ -47,8 +48,8 @@ elif os.environ.get("INSTRUCT_ZQ_COOP", "1") != "0":
         names = ["top->z picked+stored", "->published", "->candidates drawn", "->gathered", "->Dirichlet (per wave)"]
         if os.environ.get("INSTRUCT_ZQ_PIPE", "1") != "0":
             # draw waves: 0 top, 1 picked, 2 published, 6 candidates; control wave: 4 top, 3 gathered, 5 Dirichlet done
-            order = [0, 1, 2, 6]
-            names = ["draw: top->z picked", "->published+stored", "->candidates drawn"]
+            order = [0, 1, 2, 6, 7]
+            names = ["draw: top->z picked", "->stored", "->candidates drawn", "->their counts published"]
             dc = np.diff(s[:, [4, 3, 5]], axis=1)
             for n, col in zip(["ctrl: top->gathered", "->Dirichlet"], dc.T):
                 q = np.percentile(col, [5, 25, 50, 75, 95, 99])
