@@ -2205,6 +2205,20 @@ __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh bas
 		const bool covered = offi + 2ull * (unsigned)nvalid + 1024ull <= d.tape_len;
 		const bool valid = (cl.a0 != 0xff);
 		STAMP(i, 0);
+		/* ---- first in the queue: the uniforms of the next individual's candidates and its frequency rows ---- */
+		const unsigned long long nbase = offi + 2ull * (unsigned)nvalid + 2ull * (unsigned)K; /* every gamma: >= one attempt of two uniforms */
+		const bool nvalidc = (i + 1 < d.N) && (nbase + 2ull * (C - 1) + 2ull * (unsigned)nnvalid + 1024ull <= d.tape_len);
+		const bool nvalidl = (nl.a0 != 0xff);
+		const unsigned nrank = nl.rw + (unsigned)__popcll(__ballot(nvalidl) & ((1ull << lane) - 1ull));
+		double xs[2 * C];
+#pragma unroll
+		for (int k = 0; k < 2 * C; k++) xs[k] = 0.5;
+		if (nvalidc && nvalidl) {
+			const double *tp = d.tape + nbase + 2ull * nrank;
+#pragma unroll
+			for (int k = 0; k < 2 * C; k++) xs[k] = tp[k];
+		}
+		fetch_rows(nl);
 		/* ---- this individual's Z: a candidate drawn earlier (its counts left then), or the plain path ---- */
 		const unsigned long long dc = offi - cbase;
 		const bool hit = cvalid && offi >= cbase && !(dc & 1ull) && dc < 2ull * C;
@@ -2255,19 +2269,6 @@ __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh bas
 		if (!covered && t == 0) cb->overflow_flag = 1;
 		STAMP(i, 2);
 		/* ---- the next individual's candidates ---- */
-		const unsigned long long nbase = offi + 2ull * (unsigned)nvalid + 2ull * (unsigned)K; /* every gamma: >= one attempt of two uniforms */
-		const bool nvalidc = (i + 1 < d.N) && (nbase + 2ull * (C - 1) + 2ull * (unsigned)nnvalid + 1024ull <= d.tape_len);
-		const bool nvalidl = (nl.a0 != 0xff);
-		const unsigned nrank = nl.rw + (unsigned)__popcll(__ballot(nvalidl) & ((1ull << lane) - 1ull));
-		double xs[2 * C];
-#pragma unroll
-		for (int k = 0; k < 2 * C; k++) xs[k] = 0.5;
-		if (nvalidc && nvalidl) {
-			const double *tp = d.tape + nbase + 2ull * nrank;
-#pragma unroll
-			for (int k = 0; k < 2 * C; k++) xs[k] = tp[k];
-		}
-		fetch_rows(nl);
 		fetch_geno(i + 2, ml);
 		/* the next Dirichlet's stretch of the tape (its start is known up to this Dirichlet's rejected attempts: 160
 		 * uniforms cover that), so that the control wave finds it in L2 */
