@@ -145,6 +145,15 @@ int isg_get_poly_geno(isg_ctx *ctx, int32_t *geno);               /* [N][L][4] i
 int isg_get_poly_gs(isg_ctx *ctx, int32_t *gs, int32_t *gcount);  /* table row stride; genotypes per locus [L] (may be NULL) */
 int isg_get_poly_table(isg_ctx *ctx, int which, float *out);      /* 0 exfreq, 1 genofreq: float [K][L][gs] */
 
+/* CHAIN running means on the device: allocate_chn + initialize_chn (mcmc.c:588-738) and store_chn (mcmc.c:1320-1456)
+ * for everything that is O(N K) or O(K L A) -- qq, qq2, indvlkh, gen, gen2 and, with_freq (-pf 1, ploidy 2), freq,
+ * freq2.  Same multiplicative running mean, same bits as the reference's host loop; a stored step moves nothing
+ * over PCIe.  The scalars (totallkh, totallkh2) and the rate vectors stay with the caller (instruct_amd/host).
+ * isg_store_fetch: null pointers are skipped; freq / freq2 come back as [K][L][Amax]; *steps = stored steps. */
+int isg_store_begin(isg_ctx *ctx, int with_freq);
+int isg_store_step(isg_ctx *ctx);
+int isg_store_fetch(isg_ctx *ctx, double *qq, double *qq2, double *indvlkh, double *gen, double *gen2, double *freq, double *freq2, long *steps);
+
 /* per-kernel device timing with HIP events on the launch stream (bench.py roofline) */
 int isg_profile_enable(isg_ctx *ctx, int on);
 int isg_profile_count(isg_ctx *ctx);

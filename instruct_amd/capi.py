@@ -24,6 +24,7 @@ EXPORTS = [
     "isg_get_alpha", "isg_get_totallkh", "isg_get_amax", "isg_set_z", "isg_set_freq", "isg_set_qq",
     "isg_set_generation", "isg_set_self_rates", "isg_set_alpha", "isg_keyed_layout", "isg_profile_enable",
     "isg_profile_count", "isg_profile_get", "isg_profile_reset", "isg_gelman_rubin", "isg_selftest",
+    "isg_store_begin", "isg_store_step", "isg_store_fetch",
     "isg_ctx_create_poly", "isg_poly_update_geno", "isg_get_poly_geno", "isg_get_poly_gs", "isg_get_poly_table",
 ]
 
@@ -210,6 +211,24 @@ class HipChain:
         out = (C.c_uint64 * 9)()
         self._chk(self.lib.isg_keyed_layout(self.h, out))
         return tuple(out)
+
+    # --- CHAIN running means on the device (store_chn, mcmc.c:1320-1456)
+    def store_begin(self, with_freq=False):
+        self._chk(self.lib.isg_store_begin(self.h, 1 if with_freq else 0))
+
+    def store_step(self):
+        self._chk(self.lib.isg_store_step(self.h))
+
+    def store_fetch(self, want=("qq", "qq2", "indvlkh", "gen", "gen2")):
+        """dict of the requested running means (+ "steps"); freq / freq2 as [K][L][Amax]"""
+        N, K, L = self.N, self.K, self.L
+        shapes = {"qq": (N, K), "qq2": (N, K), "indvlkh": (N,), "gen": (N,), "gen2": (N,), "freq": (K, L, self.Amax), "freq2": (K, L, self.Amax)}
+        out = {k: np.zeros(shapes[k], dtype=np.float64) for k in want}
+        steps = C.c_long()
+        args = [_ptr(out[k]) if k in out else None for k in ("qq", "qq2", "indvlkh", "gen", "gen2", "freq", "freq2")]
+        self._chk(self.lib.isg_store_fetch(self.h, *args, C.byref(steps)))
+        out["steps"] = steps.value
+        return out
 
     # --- profiling
     def profile(self, on=True):

@@ -142,6 +142,11 @@ struct isg_ctx {
 	std::vector<double> ratios_h;
 	/* which host mirrors are current */
 	bool h_qq, h_gen, h_S, h_lkh;
+	/* CHAIN running means kept on the device (isg_store_*): qq, qq2 [N][K]; indvlkh, gen, gen2 [N]; freq, freq2 in the
+	 * device order of d.freq */
+	double *st_qq = nullptr, *st_qq2 = nullptr, *st_lkh = nullptr, *st_gen = nullptr, *st_gen2 = nullptr, *st_freq = nullptr, *st_freq2 = nullptr;
+	long st_step = 0;
+	bool st_on = false;
 	/* profiling */
 	bool prof;
 	std::vector<ProfEntry> prof_entries;
@@ -2614,6 +2619,7 @@ static int inbreed_update_F_POP(isg_ctx *c);
 static int inbreed_cal_lkh(isg_ctx *c);
 static int inbreed_alloc(isg_ctx *c);
 static void inbreed_free(isg_ctx *c);
+static void store_free(isg_ctx *c);
 #define NOT_POLY(c, what) if ((c)->poly) return fail(what ": not part of the ploidy 4 chain (poly_geno.c:98-116)")
 
 extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, const int32_t *geno, const int32_t *missindx, isg_ctx **out)
@@ -2776,6 +2782,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->cfg.device);
 	(void)hipStreamSynchronize(c->stream);
+	store_free(c);
 	if (c->poly) {
 		poly_ctx_destroy(c);
 		prof_collect(c);
@@ -3525,6 +3532,123 @@ extern "C" int isg_get_poly_table(isg_ctx *c, int which, float *out)
 }
 
 /* ---- profiling ---- */
+/* ---- store_chn on the device (mcmc.c:1320-1456; allocate_chn + initialize_chn, mcmc.c:588-738) ----
+ * The reference keeps multiplicative running means  m <- m * ((n + x / m) / (n + 1)), seeded with 1  (mcmc.c:1327-1332 and
+ * every block after it).  The same two divisions and one multiplication in double, no contraction: the same bits as
+ * the host loop (tests/test_gpu_parity.py::test_store_chn_on_device...).  Only what is O(N K) or O(K L A) lives here;
+ * the scalars and the per-cluster rates stay with the caller. */
+__device__ __forceinline__ void runmean_dev(double *m, double x, double n, double n1)
+{
+	const double v = *m;
+	*m = (v != 0) ? v * ((n + x / v) / n1) : x / n1;
+}
+__global__ void k_store_fill(double *p, size_t n, double v)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+__global__ void k_store_chn(const double *qq, double *mqq, double *mqq2, size_t nqq, const double *lkh, double *mlkh, const int *gen, double *mgen,
+			    double *mgen2, size_t nind, const double *freq, double *mfreq, double *mfreq2, size_t nfreq, double n, double n1)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (mqq && i < nqq) {
+		const double x = qq[i];
+		runmean_dev(&mqq[i], x, n, n1);
+		runmean_dev(&mqq2[i], x * x, n, n1);
+	}
+	if (i < nind) {
+		runmean_dev(&mlkh[i], lkh[i], n, n1);
+		if (mgen) {
+			const int g = gen[i];
+			runmean_dev(&mgen[i], (double)g, n, n1);
+			runmean_dev(&mgen2[i], (double)(g * g), n, n1);
+		}
+	}
+	if (mfreq && i < nfreq) {
+		const double x = freq[i];
+		runmean_dev(&mfreq[i], x, n, n1);
+		runmean_dev(&mfreq2[i], x * x, n, n1);
+	}
+}
+static void store_free(isg_ctx *c)
+{
+	(void)hipFree(c->st_qq); (void)hipFree(c->st_qq2); (void)hipFree(c->st_lkh); (void)hipFree(c->st_gen); (void)hipFree(c->st_gen2);
+	(void)hipFree(c->st_freq); (void)hipFree(c->st_freq2);
+	c->st_qq = c->st_qq2 = c->st_lkh = c->st_gen = c->st_gen2 = c->st_freq = c->st_freq2 = nullptr;
+	c->st_on = false;
+	c->st_step = 0;
+}
+static int store_alloc_ones(isg_ctx *c, double **p, size_t n)
+{
+	HIPCHK(hipMalloc((void **)p, sizeof(double) * n));
+	hipLaunchKernelGGL(k_store_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, *p, n, 1.0);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int isg_store_begin(isg_ctx *c, int with_freq)
+{
+	HIPCHK(hipSetDevice(c->cfg.device));
+	store_free(c);
+	const size_t N = (size_t)c->cfg.N, K = (size_t)c->cfg.K;
+	const bool has_qq = c->poly || c->cfg.mode != 0, has_gen = !c->poly && (c->cfg.mode == 2 || c->cfg.mode == 3);
+	if (with_freq && c->poly) return fail("isg_store_begin: allele frequencies are only accumulated for ploidy 2 (mcmc.c:1436)");
+	if (has_qq && (store_alloc_ones(c, &c->st_qq, N * K) || store_alloc_ones(c, &c->st_qq2, N * K))) return 1;
+	if (store_alloc_ones(c, &c->st_lkh, N)) return 1;
+	if (has_gen && (store_alloc_ones(c, &c->st_gen, N) || store_alloc_ones(c, &c->st_gen2, N))) return 1;
+	if (with_freq) {
+		const size_t nf = (size_t)c->cfg.L * c->Amax * c->d.KP;
+		if (store_alloc_ones(c, &c->st_freq, nf) || store_alloc_ones(c, &c->st_freq2, nf)) return 1;
+	}
+	c->st_on = true;
+	c->st_step = 0;
+	return 0;
+}
+extern "C" int isg_store_step(isg_ctx *c)
+{
+	HIPCHK(hipSetDevice(c->cfg.device));
+	if (!c->st_on) return fail("isg_store_step: isg_store_begin first");
+	if (c->poly && c->poly->freq_host && c->st_freq) return fail("isg_store_step: ploidy 4 keeps no frequency means");
+	const size_t N = (size_t)c->cfg.N, K = (size_t)c->cfg.K, nqq = c->st_qq ? N * K : 0, nf = c->st_freq ? (size_t)c->cfg.L * c->Amax * c->d.KP : 0;
+	size_t n = nqq > N ? nqq : N;
+	if (nf > n) n = nf;
+	prof_begin(c);
+	hipLaunchKernelGGL(k_store_chn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->d.qq, c->st_qq, c->st_qq2, nqq,
+			   (const double *)c->d.indvlkh, c->st_lkh, (const int *)c->d.gen, c->st_gen, c->st_gen2, N, (const double *)c->d.freq, c->st_freq, c->st_freq2,
+			   nf, (double)c->st_step, (double)(1 + c->st_step));
+	prof_end(c, "k_store_chn");
+	HIPCHK(hipGetLastError());
+	c->st_step++;
+	return 0;
+}
+/* null pointers are skipped; freq / freq2 come back in the reference's order [K][L][Amax] */
+extern "C" int isg_store_fetch(isg_ctx *c, double *qq, double *qq2, double *indvlkh, double *gen, double *gen2, double *freq, double *freq2, long *steps)
+{
+	HIPCHK(hipSetDevice(c->cfg.device));
+	if (!c->st_on) return fail("isg_store_fetch: isg_store_begin first");
+	const size_t N = (size_t)c->cfg.N, K = (size_t)c->cfg.K;
+	if ((qq || qq2) && !c->st_qq) return fail("isg_store_fetch: this mode keeps no qq means");
+	if ((gen || gen2) && !c->st_gen) return fail("isg_store_fetch: this mode keeps no generation means");
+	if ((freq || freq2) && !c->st_freq) return fail("isg_store_fetch: isg_store_begin was called without frequencies");
+	if (qq) HIPCHK(hipMemcpyAsync(qq, c->st_qq, sizeof(double) * N * K, hipMemcpyDeviceToHost, c->stream));
+	if (qq2) HIPCHK(hipMemcpyAsync(qq2, c->st_qq2, sizeof(double) * N * K, hipMemcpyDeviceToHost, c->stream));
+	if (indvlkh) HIPCHK(hipMemcpyAsync(indvlkh, c->st_lkh, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+	if (gen) HIPCHK(hipMemcpyAsync(gen, c->st_gen, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+	if (gen2) HIPCHK(hipMemcpyAsync(gen2, c->st_gen2, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	for (int which = 0; which < 2; which++) {
+		double *dst = which ? freq2 : freq;
+		if (!dst) continue;
+		const int L = c->cfg.L, A = c->Amax, KP = c->d.KP;
+		HIPCHK(hipMemcpyAsync(c->freq_stage.data(), which ? c->st_freq2 : c->st_freq, sizeof(double) * (size_t)L * A * KP, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		for (int k = 0; k < (int)K; k++)
+			for (int j = 0; j < L; j++)
+				for (int a = 0; a < A; a++) dst[((size_t)k * L + j) * A + a] = c->freq_stage[((size_t)j * A + a) * KP + k];
+	}
+	if (steps) *steps = c->st_step;
+	return 0;
+}
+
 extern "C" int isg_profile_enable(isg_ctx *c, int on) { c->prof = on != 0; return 0; }
 extern "C" int isg_profile_count(isg_ctx *c) { prof_collect(c); return (int)c->prof_entries.size(); }
 extern "C" int isg_profile_get(isg_ctx *c, int idx, char *name, int cap, double *ms, long *n)

@@ -218,6 +218,22 @@ static void runmean(double *m, double x, long step)
 	else *m = x / (1 + step);
 }
 
+/* the part of store_chn that stays on the host when the O(N K) / O(K L A) running means are kept on the device
+ * (isg_store_step): the two scalars and the rate vector */
+static void store_chn_small(CHAIN *c, UPMCMC *p, SEQDATA data)
+{
+	int inb, j;
+	long n = rate_len(data, &inb), s = c->step;
+	runmean(&c->totallkh, p->totallkh, s);
+	runmean(&c->totallkh2, p->totallkh * p->totallkh, s);
+	for (j = 0; j < n; j++) {
+		double x = inb ? p->inbreed[j] : p->self_rates[j];
+		runmean(inb ? &c->inbreed[j] : &c->self_rates[j], x, s);
+		runmean(inb ? &c->inbreed2[j] : &c->self_rates2[j], x * x, s);
+	}
+	c->step++;
+}
+
 void store_chn(CHAIN *c, UPMCMC *p, SEQDATA data) /* mcmc.c:1320-1456 */
 {
 	int inb, i, j, k;
@@ -396,7 +412,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	double *freqflat = data.print_freq == 1 ? (double *)malloc(sizeof(double) * (size_t)K * L * A) : NULL;
 	const int tetra = (data.ploid == 4), inbr = (data.ploid == 2 && data.mode == 4), indv = (data.ploid == 2 && data.mode == 3),
 		  finb = (data.ploid == 2 && data.mode == 5);
-	int i, j, k;
+	int i, j, k, stored_on_device = 0;
 
 	memset(&mchain, 0, sizeof(mchain));
 	memset(&node, 0, sizeof(node));
@@ -436,9 +452,12 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 		want_state = stored || data.print_iter == 1 || cnt_step == data.nstep_check_empty_cluster;
 		if (want_state) {
 			isg_get_totallkh(ctx, &node.totallkh);
-			isg_get_qq(ctx, qqflat);
-			for (i = 0; i < N; i++)
-				for (k = 0; k < K; k++) node.qq[i][k] = qqflat[(size_t)i * K + k];
+			/* qq itself is only looked at by print_info and check_empty_cluster; its running means are kept on the device */
+			if (data.print_iter == 1 || cnt_step == data.nstep_check_empty_cluster || (stored && cnt_step + 1 == data.nstep_check_empty_cluster)) {
+				isg_get_qq(ctx, qqflat);
+				for (i = 0; i < N; i++)
+					for (k = 0; k < K; k++) node.qq[i][k] = qqflat[(size_t)i * K + k];
+			}
 			if (data.mode == 2 || tetra) {
 				isg_get_self_rates(ctx, node.self_rates);
 				isg_get_state(ctx, node.state);
@@ -451,17 +470,15 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 			if (finb) isg_get_self_rates(ctx, node.inbreed);
 		}
 		if (data.print_iter == 1) print_info(&node, data, step, initial.update);
-		if (step == initial.burnin - 1) allocate_chn(&mchain, data);
+		if (step == initial.burnin - 1) {
+			allocate_chn(&mchain, data);
+			if (isg_store_begin(ctx, data.print_freq == 1 && !tetra)) hip_fail("isg_store_begin");
+			stored_on_device = 1;
+		}
 		if (stored) {
-			isg_get_indvlkh(ctx, node.indvlkh);
-			if ((data.mode == 2 || data.mode == 3) && !tetra) isg_get_generation(ctx, node.generation);
-			if (data.print_freq == 1) {
-				if (isg_get_freq(ctx, freqflat)) hip_fail("isg_get_freq");
-				for (k = 0; k < K; k++)
-					for (j = 0; j < L; j++)
-						for (i = 0; i < data.allelenum[j]; i++) node.freq[k][j][i] = freqflat[((size_t)k * L + j) * A + i];
-			}
-			store_chn(&mchain, &node, data);
+			/* store_chn (mcmc.c:1320-1456): qq, qq2, indvlkh, gen, gen2, freq, freq2 on the device, the rest here */
+			if (isg_store_step(ctx)) hip_fail("isg_store_step");
+			store_chn_small(&mchain, &node, data);
 			if (cnt_step < cvg->ckrep) cvg->convg_ld[chn * cvg->ckrep + cnt_step] = node.totallkh;
 			cnt_step++;
 		}
@@ -479,6 +496,30 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	}
 	isg_get_seeds(ctx, seeds);
 	setseeds((int)seeds[0], (int)seeds[1], (int)seeds[2]);
+	if (stored_on_device) { /* the running means come back once, into the CHAIN the caller will read */
+		const int with_gen = has_gen(data), with_freq = (data.print_freq == 1 && !tetra);
+		double *q1 = (double *)malloc(sizeof(double) * (size_t)N * K), *q2 = (double *)malloc(sizeof(double) * (size_t)N * K);
+		double *f2 = with_freq ? (double *)malloc(sizeof(double) * (size_t)K * L * A) : NULL;
+		long nst = 0;
+		if (isg_store_fetch(ctx, q1, q2, mchain.indvlkh, with_gen ? mchain.gen : NULL, with_gen ? mchain.gen2 : NULL, with_freq ? freqflat : NULL, f2, &nst))
+			hip_fail("isg_store_fetch");
+		if (nst != mchain.step) nrerror("The number of steps stored on the device is not the same as counted");
+		for (i = 0; i < N; i++)
+			for (k = 0; k < K; k++) {
+				mchain.qq[i][k] = q1[(size_t)i * K + k];
+				mchain.qq2[i][k] = q2[(size_t)i * K + k];
+			}
+		if (with_freq)
+			for (k = 0; k < K; k++)
+				for (j = 0; j < L; j++)
+					for (i = 0; i < data.allelenum[j]; i++) {
+						mchain.freq[k][j][i] = freqflat[((size_t)k * L + j) * A + i];
+						mchain.freq2[k][j][i] = f2[((size_t)k * L + j) * A + i];
+					}
+		free(q1);
+		free(q2);
+		free(f2);
+	}
 
 	free_dmatrix(node.qq, 0, N - 1, 0, K - 1);
 	free_dvector(node.indvlkh, 0, N - 1);

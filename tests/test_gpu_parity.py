@@ -600,3 +600,43 @@ def test_full_size_properties_config3(full_size):
             h.close()
     # keyed schedule: two runs with the same seeds are identical to the last bit (order-independent sums)
     assert hashes[capi.SCHED_KEYED][0] == hashes[capi.SCHED_KEYED][1]
+
+
+def _runmean(m, x, n):
+    """the reference's multiplicative running mean (mcmc.c:1327-1332), element-wise in IEEE double"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(m != 0, m * ((n + x / m) / (1 + n)), x / (1 + n))
+
+
+@pytest.mark.parametrize("sched", [capi.SCHED_REPLAY, capi.SCHED_KEYED])
+def test_store_chn_on_device_equals_the_host_running_means(sched):
+    """isg_store_step keeps CHAIN.qq/qq2/indvlkh/gen/gen2/freq/freq2 on the device: same bits as store_chn's loop
+    (mcmc.c:1320-1456) applied to the downloaded state"""
+    N, L, K = 60, 130, 4
+    geno, an, mi = synth.code_diploid(synth.raw_alleles(N, L, K, 2, 3, 0.05, 5))
+    h = capi.HipChain(geno, an, mi, K, rng_sched=sched)
+    h.setseeds(13, 4, 1972)
+    h.chain_init(np.array([h.ran1() for _ in range(K)], dtype=np.float32))
+    for _ in range(3):
+        h.iteration()
+    h.store_begin(with_freq=True)
+    ref = {k: np.ones(s) for k, s in (("qq", (N, K)), ("qq2", (N, K)), ("indvlkh", (N,)), ("gen", (N,)), ("gen2", (N,)),
+                                      ("freq", (K, L, h.Amax)), ("freq2", (K, L, h.Amax)))}
+    for n in range(7):
+        h.iteration()
+        if n % 2:
+            h.iteration()  # a thinning step in between
+        h.store_step()
+        qq, lk, g, f = h.qq(), h.indvlkh(), h.generation().astype(np.int64), h.freq()
+        for key, x in (("qq", qq), ("qq2", qq * qq), ("indvlkh", lk), ("gen", g.astype(np.float64)), ("gen2", (g * g).astype(np.float64)),
+                       ("freq", f), ("freq2", f * f)):
+            ref[key] = _runmean(ref[key], x, n)
+    got = h.store_fetch(("qq", "qq2", "indvlkh", "gen", "gen2", "freq", "freq2"))
+    assert got["steps"] == 7
+    for key in ref:
+        a, b = got[key], ref[key]
+        if key.startswith("freq"):  # only alleles that exist are part of CHAIN.freq (mcmc.c:1438-1441)
+            mask = np.arange(h.Amax)[None, None, :] < np.asarray(an)[None, :, None]
+            a, b = a[np.broadcast_to(mask, a.shape)], b[np.broadcast_to(mask, b.shape)]
+        assert np.array_equal(a, b), key
+    h.close()
