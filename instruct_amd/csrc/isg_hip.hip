@@ -136,6 +136,8 @@ struct isg_ctx {
 	int pipe; /* 1: draw waves + one control wave per workgroup (k_zq_pipe; INSTRUCT_ZQ_PIPE=0 disables) */
 	int pipe_xcd; /* 1: its workgroups on one XCD when they fit (INSTRUCT_ZQ_PIPE_XCD=0 disables) */
 	unsigned long long *d_pipe = nullptr; /* its granules (one line per publishing wave) */
+	unsigned long long *d_spop = nullptr; /* k_spop_tree: limbs of the 2^K exact sums */
+	int spop_tree = 1;                    /* INSTRUCT_SPOP_TREE=0: the one-workgroup k_spop always */
 	size_t pipe_cap = 0;
 	int *d_state;
 	double *d_ratios, *d_total;
@@ -160,6 +162,19 @@ struct isg_ctx {
 /* ------------------------------------------------------------------------------------------ */
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+
+/* sum of x over the 64 lanes, as a wave-uniform value: rotations inside the rows of 16 lanes (every lane of a row
+ * ends up with the row's sum), then the four rows through SGPRs.  All lanes must be active. */
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned x)
+{
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false); /* row_ror:1 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false); /* row_ror:2 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false); /* row_ror:4 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false); /* row_ror:8 */
+	return (unsigned)__builtin_amdgcn_readlane((int)x, 0) + (unsigned)__builtin_amdgcn_readlane((int)x, 16) +
+	       (unsigned)__builtin_amdgcn_readlane((int)x, 32) + (unsigned)__builtin_amdgcn_readlane((int)x, 48);
+}
+
 
 /* block-wide exclusive scan of a small per-thread count; returns prefix, *total = block sum */
 template <int BLOCK>
@@ -935,6 +950,8 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 	int wcnt[KMAX];
 #pragma unroll
 	for (int m = 0; m < KMAX; m++) wcnt[m] = 0;
+	unsigned long long pc0 = 0, pc1 = 0;
+	unsigned npass = 0;
 	const int par = CHAIN ? (i & 1) : 0;
 	const size_t rowb = (size_t)d.Lp * 2;
 	const uint8_t *grow = d.geno + (size_t)i * rowb;
@@ -1070,10 +1087,22 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 		for (int l = 0; l < ISG_LPT; l++) {
 			const bool valid = (((unsigned)(gb >> (16 * l)) & 0xff) != 0xff);
 			const int z0 = valid ? zz[2 * l] : 0xff, z1 = valid ? zz[2 * l + 1] : 0xff; /* 0xff: locus unused */
+			if (KMAX <= 8) { /* per-lane counters, 16 bits per cluster (a ballot + scalar popcount per cluster and copy stalls the wave ~80 cycles each) */
+				const unsigned long long i0 = valid ? (1ull << (16 * (z0 & 3))) : 0ull, i1 = valid ? (1ull << (16 * (z1 & 3))) : 0ull;
+				pc0 += ((z0 & 4) ? 0ull : i0) + ((z1 & 4) ? 0ull : i1);
+				if (KMAX > 4) pc1 += ((z0 & 4) ? i0 : 0ull) + ((z1 & 4) ? i1 : 0ull);
+			} else {
+#pragma unroll
+				for (int m = 0; m < KMAX; m++)
+					if (m < K) wcnt[m] += __popcll(__ballot(z0 == m)) + __popcll(__ballot(z1 == m));
+			}
+			zb = (zb & ~(0xffffull << (16 * l))) | ((unsigned long long)(z0 | (z1 << 8)) << (16 * l));
+		}
+		if (KMAX <= 8 && (++npass & 1023) == 0) { /* 8 copies per pass: the 16-bit fields are emptied long before they can wrap */
 #pragma unroll
 			for (int m = 0; m < KMAX; m++)
-				if (m < K) wcnt[m] += __popcll(__ballot(z0 == m)) + __popcll(__ballot(z1 == m));
-			zb = (zb & ~(0xffffull << (16 * l))) | ((unsigned long long)(z0 | (z1 << 8)) << (16 * l));
+				if (m < K) wcnt[m] += (int)wave_sum_u32((unsigned)(((m < 4 ? pc0 : pc1) >> (16 * (m & 3))) & 0xffffu));
+			pc0 = pc1 = 0;
 		}
 		if (j0 < d.Lp) {
 			uint2 zo;
@@ -1084,6 +1113,11 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 		gb = gnext;
 	}
 	STAMP(i, 1);
+	if (KMAX <= 8) {
+#pragma unroll
+		for (int m = 0; m < KMAX; m++)
+			if (m < K) wcnt[m] += (int)wave_sum_u32((unsigned)(((m < 4 ? pc0 : pc1) >> (16 * (m & 3))) & 0xffffu));
+	}
 	/* qqnum[i][m] (mcmc.c:1176-1194): one LDS add per wave and cluster into the (pre-zeroed) buffer */
 	STAMP(i, 2);
 	if (lane_id() == 0) {
@@ -1963,18 +1997,6 @@ __global__ void __launch_bounds__(256) k_zq_spec(DevView d, isg_wh base, double 
 	if (g == 0 && t == 0) *pos_out = off;
 }
 
-/* sum of x over the 64 lanes, as a wave-uniform value: rotations inside the rows of 16 lanes (every lane of a row
- * ends up with the row's sum), then the four rows through SGPRs.  All lanes must be active. */
-__device__ __forceinline__ unsigned wave_sum_u32(unsigned x)
-{
-	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false); /* row_ror:1 */
-	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false); /* row_ror:2 */
-	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false); /* row_ror:4 */
-	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false); /* row_ror:8 */
-	return (unsigned)__builtin_amdgcn_readlane((int)x, 0) + (unsigned)__builtin_amdgcn_readlane((int)x, 16) +
-	       (unsigned)__builtin_amdgcn_readlane((int)x, 32) + (unsigned)__builtin_amdgcn_readlane((int)x, 48);
-}
-
 /* the same sum in every lane: rotations inside the rows of 16 lanes, then the rows through two cross-lane exchanges */
 __device__ __forceinline__ unsigned wave_allsum_u32(unsigned x)
 {
@@ -2489,6 +2511,107 @@ __global__ void __launch_bounds__(BLOCK) k_spop(DevView d, double *S, int *state
 	if (t == 0) *used_out = c.used;
 }
 
+/*
+ * update_S_POP for -e 1 and K <= 6, spread over the chip.  The proposal of step j is a reflected +-0.05 step from the
+ * cluster's OWN current rate (mcmc.c:939-945), and a step consumes exactly two uniforms: all K proposed values are
+ * known before the first decision.  The vector step j evaluates proposal() at depends on which earlier steps were
+ * accepted -- 2^j possibilities -- so all 2^K - 1 of them (+ the current vector) are evaluated at once, each an
+ * order-independent exact sum over the individuals (same terms, same accumulator as dev_proposal), and k_spop_decide
+ * then walks the K Metropolis steps in order on one lane.  Evaluation id: 0 = current rates; 2^j + h = step j with
+ * acceptance history h (bit m = step m accepted).
+ */
+#define ISG_SPOP_TREE_K 6
+__device__ __forceinline__ double spop_proposed(double cur, double u)
+{
+	double v = u * 2 * 0.05 - 0.05;
+	v += cur;
+	if (v <= 0.0) v = 0.0 - v;
+	else if (v >= 1.0) v = 1.0 - (v - 1.0);
+	return v;
+}
+__global__ void __launch_bounds__(256) k_spop_tree(DevView d, const double *S, isg_wh start, unsigned long long *limbs /* [2^K][5], zeroed */)
+{
+	__shared__ double Scur[ISG_SPOP_TREE_K], V[ISG_SPOP_TREE_K];
+	const int K = d.K, t = threadIdx.x;
+	if (t < K) {
+		Scur[t] = S[t];
+		isg_wh s = isg_wh_jump(d.tab, start, 2ull * (unsigned)t);
+		V[t] = spop_proposed(Scur[t], isg_wh_next(&s));
+	}
+	__syncthreads();
+	const int i = blockIdx.x * 256 + t;
+	double q[ISG_SPOP_TREE_K];
+	double gm1 = 0.0;
+#pragma unroll
+	for (int m = 0; m < ISG_SPOP_TREE_K; m++) q[m] = (i < d.N && m < K) ? d.qq[(size_t)i * K + m] : 0.0;
+	if (i < d.N) gm1 = (double)(d.gen[i] - 1);
+	{
+		const int e = blockIdx.y; /* one evaluation per workgroup row */
+		int j = -1, h = 0;
+		if (e) {
+			j = 31 - __builtin_clz((unsigned)e);
+			h = e - (1 << j);
+		}
+		isg_acc a;
+		isg_acc_zero(&a);
+		if (i < d.N) {
+			double temp = 0;
+#pragma unroll
+			for (int m = 0; m < ISG_SPOP_TREE_K; m++)
+				if (m < K) temp += q[m] * ((m == j || (m < j && ((h >> m) & 1))) ? V[m] : Scur[m]);
+			isg_acc_add(&a, isg_log(isg_pow(temp, gm1) * (1 - temp)));
+		}
+		AccLimbs sl = acc_to_limbs(a);
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			sl.l0 += __shfl_down(sl.l0, o, 64);
+			sl.l1 += __shfl_down(sl.l1, o, 64);
+			sl.l2 += __shfl_down(sl.l2, o, 64);
+			sl.l3 += __shfl_down(sl.l3, o, 64);
+			sl.flags |= __shfl_down(sl.flags, o, 64);
+		}
+		if (lane_id() == 0) { /* 32-bit limbs in 64-bit words: the chip-wide sums cannot carry out */
+			atomicAdd(&limbs[e * 5 + 0], sl.l0);
+			atomicAdd(&limbs[e * 5 + 1], sl.l1);
+			atomicAdd(&limbs[e * 5 + 2], sl.l2);
+			atomicAdd(&limbs[e * 5 + 3], sl.l3);
+			if (sl.flags) atomicOr(&limbs[e * 5 + 4], (unsigned long long)sl.flags);
+		}
+	}
+}
+__global__ void k_spop_decide(DevView d, double *S, isg_wh start, const unsigned long long *limbs)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	const int K = d.K;
+	auto value = [&](int e) {
+		AccLimbs sl;
+		sl.l0 = limbs[e * 5 + 0];
+		sl.l1 = limbs[e * 5 + 1];
+		sl.l2 = limbs[e * 5 + 2];
+		sl.l3 = limbs[e * 5 + 3];
+		sl.flags = (unsigned)limbs[e * 5 + 4];
+		const isg_acc a = limbs_to_acc(sl);
+		return isg_acc_value(&a);
+	};
+	double cur_ld = value(0);
+	int h = 0;
+	isg_cursor c;
+	c.s = isg_wh_jump(d.tab, start, 0);
+	c.used = 0;
+	c.tape = nullptr;
+	for (int j = 0; j < K; j++) {
+		const double v = spop_proposed(S[j], isg_cur_next(&c)); /* the same value k_spop_tree formed */
+		const double new_ld = value((1 << j) + h);
+		const double mh = isg_exp(new_ld - cur_ld);
+		const double thr = (1 > mh) ? mh : 1;
+		if (isg_cur_next(&c) < thr) {
+			S[j] = v;
+			h |= 1 << j;
+			cur_ld = new_ld;
+		}
+	}
+}
+
 /* update_alpha: the N*K factors pow(q, ralpha + n) / pow(q, n + alpha) (mcmc.c:1258); their ORDERED
  * product (overflow / NaN behaviour of the reference included) is formed on the host */
 __global__ void k_alpha_ratios(DevView d, double ralpha, double alpha, double *ratios)
@@ -2723,6 +2846,8 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 		c->xcd = (e && atoi(e) == 1) ? 1 : 0;
 		e = getenv("INSTRUCT_ZQ_PIPE");
 		c->pipe = (e && atoi(e) == 0) ? 0 : 1;
+		e = getenv("INSTRUCT_SPOP_TREE");
+		c->spop_tree = (e && atoi(e) == 0) ? 0 : 1;
 		e = getenv("INSTRUCT_ZQ_PIPE_XCD");
 		c->pipe_xcd = (e && atoi(e) == 0) ? 0 : 1;
 	}
@@ -2793,7 +2918,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	}
 	inbreed_free(c);
 	DevView &d = c->d;
-	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(d.lftab); (void)hipFree(d.lltab); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(c->d_pipe); (void)hipFree(d.cnt);
+	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(d.lftab); (void)hipFree(d.lltab); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(c->d_pipe); (void)hipFree(c->d_spop); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
 	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S); (void)hipFree(c->d_Fprop); (void)hipFree(c->d_state); (void)hipFree(c->d_ratios); (void)hipFree(c->d_total);
 	prof_collect(c);
@@ -2997,9 +3122,19 @@ extern "C" int isg_update_S_POP(isg_ctx *c)
 	if (c->poly) return poly_update_S_POP(c);
 	const int K = c->cfg.K;
 	isg_wh start = is_keyed(c) ? isg_wh_jump(&c->tab_h, c->origin, iter_base(c) + c->ky[KY_OFFS]) : c->rng;
-	prof_begin(c);
-	hipLaunchKernelGGL(k_spop<1024>, dim3(1), dim3(1024), 0, c->stream, c->d, c->d_S, c->d_state, start, c->cfg.back_refl, c->d_pos + 1);
-	prof_end(c, "k_spop");
+	if (c->cfg.back_refl == 1 && K <= ISG_SPOP_TREE_K && c->spop_tree) {
+		const size_t nb = sizeof(unsigned long long) * 5 * ((size_t)1 << K);
+		if (!c->d_spop) HIPCHK(hipMalloc((void **)&c->d_spop, sizeof(unsigned long long) * 5 * ((size_t)1 << ISG_SPOP_TREE_K)));
+		HIPCHK(hipMemsetAsync(c->d_spop, 0, nb, c->stream));
+		prof_begin(c);
+		hipLaunchKernelGGL(k_spop_tree, dim3((c->cfg.N + 255) / 256, 1u << K), dim3(256), 0, c->stream, c->d, (const double *)c->d_S, start, c->d_spop);
+		hipLaunchKernelGGL(k_spop_decide, dim3(1), dim3(64), 0, c->stream, c->d, c->d_S, start, (const unsigned long long *)c->d_spop);
+		prof_end(c, "k_spop");
+	} else {
+		prof_begin(c);
+		hipLaunchKernelGGL(k_spop<1024>, dim3(1), dim3(1024), 0, c->stream, c->d, c->d_S, c->d_state, start, c->cfg.back_refl, c->d_pos + 1);
+		prof_end(c, "k_spop");
+	}
 	HIPCHK(hipGetLastError());
 	c->h_S = false;
 	if (!is_keyed(c)) {
