@@ -2722,6 +2722,57 @@ static double host_next(isg_ctx *c)
 static void host_seek(isg_ctx *c, uint64_t pos) { c->rng = isg_wh_jump(&c->tab_h, c->origin, pos); c->raw_valid = false; }
 static void host_advance(isg_ctx *c, uint64_t n) { c->rng = isg_wh_jump(&c->tab_h, c->rng, n); c->raw_valid = false; }
 
+/*
+ * Host side of update_P in the replay schedule (the K L Dirichlets are drawn in stream order): rdirich
+ * (random.c:264-280) with the accept / reject test of rgamma2 (random.c:195-231) pre-decided in single precision,
+ * exactly as rgamma2_try_dev does on the device -- the two logarithms only feed the comparison
+ * c3 log(u1) - log(w) + w >= 1; outside a band of 2e-6 (1 + |terms|) the float value decides, inside it the double
+ * expression.  Same values, same consumption as isg_rdirich.
+ */
+static inline double host_rgamma2_try(isg_cursor *c, double alpha)
+{
+	double u1, u2, c1, c2, c3, c4, c5, w;
+	c1 = alpha - 1;
+	c2 = (alpha - 1 / (6 * alpha)) / c1;
+	c3 = 2 / c1;
+	c4 = c3 + 2;
+	c5 = 1 / isg_sqrt(alpha);
+	do {
+		u1 = isg_cur_next(c);
+		u2 = isg_cur_next(c);
+		if (alpha > 2.5) u1 = u2 + c5 * (1 - 1.86 * u1);
+	} while ((u1 >= 1) || (u1 <= 0));
+	w = c2 * u2 / u1;
+	if ((c3 * u1 + w + 1 / w) > c4) {
+		const float l1 = logf((float)u1), lw = logf((float)w);
+		const double al1 = fabs((double)l1), alw = fabs((double)lw);
+		const double dlt = (c3 * (double)l1 - (double)lw + w) - 1;
+		const double tol = 2e-6 * (fabs(c3) * (1.0 + al1) + 1.0 + alw) + 1e-12 * fabs(w);
+		bool rej;
+		if (dlt > tol) rej = true;
+		else if (dlt < -tol) rej = false;
+		else rej = (c3 * isg_log(u1) - isg_log(w) + w) >= 1;
+		if (rej) return -1;
+	}
+	return c1 * w;
+}
+static void host_rdirich(isg_cursor *c, const double *count, int n, double *out, double add)
+{
+	double sum = 0;
+	for (int k = 0; k < n; k++) {
+		const double a = count[k] + add;
+		double g = 0;
+		if (a > 1) {
+			do { g = host_rgamma2_try(c, a); } while (g < 0);
+		} else {
+			g = isg_rgamma(c, a);
+		}
+		out[k] = g;
+		sum += g;
+	}
+	for (int k = 0; k < n; k++) out[k] /= sum;
+}
+
 extern "C" const char *isg_last_error(void) { return g_err.c_str(); }
 
 /* ploidy 4 (isg_poly_hip.inc, included further down) */
@@ -3103,7 +3154,7 @@ extern "C" int isg_update_P(isg_ctx *c)
 			int Aj = c->allelenum[j];
 			if (Aj <= 1) continue;
 			for (int a = 0; a < Aj; a++) tmp[a] = (double)c->cnt_h[((size_t)j * A + a) * K + k];
-			isg_rdirich(&cur, tmp.data(), Aj, &c->freq[((size_t)k * L + j) * A], 1.0);
+			host_rdirich(&cur, tmp.data(), Aj, &c->freq[((size_t)k * L + j) * A], 1.0);
 		}
 	c->rng = cur.s;
 	c->raw_valid = false;
