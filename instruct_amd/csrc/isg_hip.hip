@@ -137,6 +137,9 @@ struct isg_ctx {
 	int pipe_xcd; /* 1: its workgroups on one XCD when they fit (INSTRUCT_ZQ_PIPE_XCD=0 disables) */
 	unsigned long long *d_pipe = nullptr; /* its granules (one line per publishing wave) */
 	unsigned long long *d_spop = nullptr; /* k_spop_tree: limbs of the 2^K exact sums */
+	std::vector<double> htape;            /* replay update_P: the host loop's uniforms (host_tape_begin) */
+	uint64_t htape_len = 0;
+	int host_tape = 1;                    /* INSTRUCT_HOST_TAPE=0: the host loop steps the generator itself */
 	int spop_tree = 1;                    /* INSTRUCT_SPOP_TREE=0: the one-workgroup k_spop always */
 	size_t pipe_cap = 0;
 	int *d_state;
@@ -2773,6 +2776,53 @@ static void host_rdirich(isg_cursor *c, const double *count, int n, double *out,
 	for (int k = 0; k < n; k++) out[k] /= sum;
 }
 
+/*
+ * The uniforms of the host's Dirichlet loop come from the device: half of that loop's time was the generator
+ * (21 ns per uniform, ~3 per gamma of ~118 ns).  k_tape writes the next `need` uniforms of the stream, the loop reads
+ * them through the cursor's tape; if they run out (they are budgeted at 3 per gamma) the loop continues with the
+ * generator from the position reached -- same values either way.
+ */
+__global__ void __launch_bounds__(256) k_tape(const isg_wh_tables *tab, isg_wh base, unsigned long long n, double *tape);
+static int host_tape_begin(isg_ctx *c, uint64_t ngamma, isg_cursor *cur)
+{
+	cur->s = c->rng;
+	cur->used = 0;
+	cur->tape = nullptr;
+	c->htape_len = 0;
+	if (!c->host_tape || ngamma < 4096) return 0;
+	const uint64_t need = 3 * ngamma + 65536;
+	if (need > c->tape_cap) {
+		if (c->d_tape) HIPCHK(hipFree(c->d_tape));
+		c->d_tape = nullptr;
+		c->tape_cap = 0;
+		HIPCHK(hipMalloc((void **)&c->d_tape, sizeof(double) * need));
+		c->tape_cap = need;
+	}
+	if (c->htape.size() < need) c->htape.resize(need);
+	prof_begin(c);
+	hipLaunchKernelGGL(k_tape, dim3((unsigned)((need + 2047) / 2048)), dim3(256), 0, c->stream, c->d.tab, c->rng, (unsigned long long)need, c->d_tape);
+	prof_end(c, "k_tape_host");
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(c->htape.data(), c->d_tape, sizeof(double) * need, hipMemcpyDeviceToHost, c->stream));
+	c->htape_len = need;
+	return 0;
+}
+/* call after the stream has been synchronised, before the loop */
+static void host_tape_attach(isg_ctx *c, isg_cursor *cur) { if (c->htape_len) cur->tape = c->htape.data(); }
+/* before each Dirichlet of n gammas: leave the tape while a comfortable margin remains (32 attempts per gamma) */
+static inline void host_tape_guard(isg_ctx *c, isg_cursor *cur, int n)
+{
+	if (cur->tape && (uint64_t)cur->used + 64ull * (unsigned)n + 64 > c->htape_len) {
+		cur->s = isg_wh_jump(&c->tab_h, c->rng, cur->used);
+		cur->tape = nullptr;
+	}
+}
+static void host_tape_end(isg_ctx *c, isg_cursor *cur)
+{
+	c->rng = cur->tape ? isg_wh_jump(&c->tab_h, c->rng, cur->used) : cur->s;
+	c->raw_valid = false;
+}
+
 extern "C" const char *isg_last_error(void) { return g_err.c_str(); }
 
 /* ploidy 4 (isg_poly_hip.inc, included further down) */
@@ -2897,6 +2947,8 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 		c->xcd = (e && atoi(e) == 1) ? 1 : 0;
 		e = getenv("INSTRUCT_ZQ_PIPE");
 		c->pipe = (e && atoi(e) == 0) ? 0 : 1;
+		e = getenv("INSTRUCT_HOST_TAPE");
+		c->host_tape = (e && atoi(e) == 0) ? 0 : 1;
 		e = getenv("INSTRUCT_SPOP_TREE");
 		c->spop_tree = (e && atoi(e) == 0) ? 0 : 1;
 		e = getenv("INSTRUCT_ZQ_PIPE_XCD");
@@ -3143,21 +3195,22 @@ extern "C" int isg_update_P(isg_ctx *c)
 	/* replay: the K*L Dirichlets consume the stream in (k, j) order with data-dependent length
 	 * (random.c:167-250), so they are drawn sequentially on the host from the counts */
 	HIPCHK(hipMemcpyAsync(c->cnt_h.data(), d.cnt, sizeof(int) * c->cnt_h.size(), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
 	isg_cursor cur;
-	cur.s = c->rng;
-	cur.used = 0;
-	cur.tape = nullptr;
+	uint64_t ngamma = 0;
+	for (int j = 0; j < L; j++) ngamma += (c->allelenum[j] > 1) ? (uint64_t)c->allelenum[j] * K : 0;
+	if (host_tape_begin(c, ngamma, &cur)) return 1;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	host_tape_attach(c, &cur);
 	std::vector<double> tmp(A);
 	for (int k = 0; k < K; k++)
 		for (int j = 0; j < L; j++) {
 			int Aj = c->allelenum[j];
 			if (Aj <= 1) continue;
 			for (int a = 0; a < Aj; a++) tmp[a] = (double)c->cnt_h[((size_t)j * A + a) * K + k];
+			host_tape_guard(c, &cur, Aj);
 			host_rdirich(&cur, tmp.data(), Aj, &c->freq[((size_t)k * L + j) * A], 1.0);
 		}
-	c->rng = cur.s;
-	c->raw_valid = false;
+	host_tape_end(c, &cur);
 	return upload_freq(c);
 }
 
