@@ -2016,7 +2016,7 @@ __device__ __forceinline__ unsigned wave_allsum_u32(unsigned x)
  * k_zq_pipe: the replay update_ZQ chain with the exchange of an individual's counts taken off the critical path.
  * Every workgroup has DW draw waves (one locus per lane) and ONE control wave; nothing but LDS words joins them.
  *   draw waves:   individual i starts where the control wave says (LDS).  Its Z is the candidate drawn earlier for
- *                 that start position (95 %), or the plain path.  Then the C candidates of individual i+1 are drawn
+ *                 that start position (92 %), or the plain path.  Then the C candidates of individual i+1 are drawn
  *                 (start = end of i's draws + 2 K + 2 c, c = rejected attempts of i's Dirichlet), the few draws the
  *                 single precision filter could not decide are redone in double, and the wave's counts of EVERY
  *                 candidate leave as tagged words -- before anybody knows which candidate it will be.
@@ -2024,7 +2024,7 @@ __device__ __forceinline__ unsigned wave_allsum_u32(unsigned x)
  *                 published while that Dirichlet and the exchange before it ran, so they have arrived or are about
  *                 to; it sums them (packed 16-bit fields add without carries: a total stays below 2 Lp < 65536), runs
  *                 the Dirichlet of i (dirichlet_wave) and posts the next start position.
- * A start position no candidate was drawn for (5 %: c >= C, a shape of exactly 1, the first individual) takes the
+ * A start position no candidate was drawn for (8 %: c >= C, a shape of exactly 1, the first individual) takes the
  * plain path: the draw waves draw Z then, publish the counts in a set of their own, and the control wave waits for
  * those.  Same Z, same counts, same consumption as k_zq_spec / k_zq_coop in every case.
  * Granules: pipe_gran(slot of the individual, publishing wave, set * W + w); set = candidate, or C for the plain path.
@@ -2033,6 +2033,9 @@ __device__ __forceinline__ unsigned wave_allsum_u32(unsigned x)
 #define ISG_PIPE_DW 3
 #endif
 #define ISG_PIPE_RMAX 6
+#ifndef ISG_PIPE_C
+#define ISG_PIPE_C 5 /* candidates per individual: 4 / 5 / 6 / 7 measured 9.78 / 9.52 / 9.70 / 9.96 k cycles per individual at config 3 */
+#endif
 #ifdef ISG_STAMPS
 #define STAMPC(i, k) do { if (threadIdx.x == 64 * DW && blockIdx.x == 0 && (i) < 4096) g_stamps[(i) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -2048,7 +2051,7 @@ __device__ __forceinline__ unsigned long long *pipe_gran(unsigned long long *pg,
 template <int KMAX, int DW>
 __global__ void __launch_bounds__(64 * (DW + 1)) k_zq_pipe(DevView d, isg_wh base, double alpha, CoopBuf *cb, unsigned long long *pg, uint64_t *pos_out, int xcd_pack)
 {
-	constexpr int BLOCK = 64 * (DW + 1), C = ISG_SPEC_C, LW = 64 * DW;
+	constexpr int BLOCK = 64 * (DW + 1), C = ISG_PIPE_C, LW = 64 * DW;
 	static_assert(KMAX <= 8 && C <= 8, "pre-filter rows in registers; candidates packed 4 bits each");
 	__shared__ ZqShared sh;
 	__shared__ unsigned long long off_sh[4]; /* start position of individual i in off_sh[i & 3] ... */
