@@ -210,6 +210,25 @@ def tetra_leg(device, steps, warmup, with_cpu):
     return res
 
 
+def measured_copy_gbs(dev):
+    """HBM bandwidth of a plain device-to-device copy on this GPU (1 GiB, read + written bytes), torch's stream"""
+    import torch
+    n = 1 << 30
+    x = torch.empty(n, dtype=torch.uint8, device=f"cuda:{dev}")
+    y = torch.empty_like(x)
+    x.zero_()
+    for _ in range(2):
+        y.copy_(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 8
+    for _ in range(reps):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,6 +293,10 @@ def main():
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(geno, K, seeds)
         head = out["replay"]
+        copy_gbs = measured_copy_gbs(local)  # the fraction against a measured device-to-device copy as well
+        for o in out.values():
+            o["roofline"]["copy_peak_measured"] = copy_gbs
+            o["roofline"]["frac_of_measured_copy"] = round(o["roofline"]["achieved"] / copy_gbs, 6)
         line = {
             "metric": "MCMC iterations/sec (update_P+update_ZQ+update_SG) at NxLxK", "value": round(head["value"], 4),
             "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
