@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 from instruct_amd import synth  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
+CLI_REF = os.path.join(os.path.relpath(REF, HERE), "InStruct_ref")  # the result files echo the command line: keep it relative
 
 # name: (N, L, K, n_alleles, missing, u, b, t, c, e, y, r, j, seeds, mode, pf, detail, commit_text)
 CASES = {
@@ -89,32 +90,60 @@ def main():
             subprocess.check_call(args, stdout=devnull)
         print(name, os.path.getsize(out), "bytes")
     # end-to-end reference CLI output for the drop-in test (result file at %.3f)
-    txt = os.path.join(HERE, "c1.txt")
-    outp = os.path.join(HERE, "c1_cli_output.txt")
-    cmd = [os.path.join(REF, "InStruct_ref"), "-d", txt, "-o", outp, "-K", "3", "-L", "100", "-N", "50", "-p", "2",
+    # (this one was committed with absolute paths on its command-line echo; kept so that regenerating reproduces the bytes)
+    cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "c1.txt"), "-o", os.path.join(HERE, "c1_cli_output.txt"), "-K", "3", "-L", "100", "-N", "50", "-p", "2",
            "-u", "200", "-b", "100", "-t", "10", "-c", "2", "-v", "2", "-g", "1", "-r", "5", "-j", "5",
            "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "1"]
     with open(os.devnull, "w") as devnull:
         subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
-    cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "c1.txt"), "-o", os.path.join(HERE, "c1_kscan_output.txt")] + KSCAN_CLI
+    cmd = [CLI_REF, "-d", "c1.txt", "-o", "c1_kscan_output.txt"] + KSCAN_CLI
     with open(os.devnull, "w") as devnull:
         subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
-    cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "c1.txt"), "-o", os.path.join(HERE, "c1_mode4_cli_output.txt")] + MODE4_CLI
+    cmd = [CLI_REF, "-d", "c1.txt", "-o", "c1_mode4_cli_output.txt"] + MODE4_CLI
     with open(os.devnull, "w") as devnull:
         subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
-    cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "c1.txt"), "-o", os.path.join(HERE, "c1_mode3_cli_output.txt")] + MODE3_CLI
+    cmd = [CLI_REF, "-d", "c1.txt", "-o", "c1_mode3_cli_output.txt"] + MODE3_CLI
     with open(os.devnull, "w") as devnull:
         subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
-    cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "c1.txt"), "-o", os.path.join(HERE, "c1_mode5_cli_output.txt")] + MODE5_CLI
+    cmd = [CLI_REF, "-d", "c1.txt", "-o", "c1_mode5_cli_output.txt"] + MODE5_CLI
     with open(os.devnull, "w") as devnull:
         subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
-    cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "c1.txt"), "-o", os.path.join(HERE, "c1_mode0_cli_output.txt")] + MODE0_CLI
+    cmd = [CLI_REF, "-d", "c1.txt", "-o", "c1_mode0_cli_output.txt"] + MODE0_CLI
     with open(os.devnull, "w") as devnull:
         subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
+    synth.write_text_diploid(os.path.join(HERE, "ec1.txt"), ec1_data())
+    for name, (data, cli) in STDOUT_CLI.items():
+        if os.path.exists(os.path.join(HERE, name + "_cli_output.txt")):
+            os.unlink(os.path.join(HERE, name + "_cli_output.txt"))
+        cmd = [CLI_REF, "-d", data, "-o", name + "_cli_output.txt"] + cli
+        with open(os.path.join(HERE, name + "_cli_stdout.txt"), "wb") as so:
+            subprocess.check_call(cmd, stdout=so, cwd=HERE)
     # same for the ploidy 4 driver (mcmc_POP_tetra_selfing)
-    cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "t1.txt"), "-o", os.path.join(HERE, "t1_cli_output.txt")] + TETRA_CLI
+    cmd = [CLI_REF, "-d", "t1.txt", "-o", "t1_cli_output.txt"] + TETRA_CLI
     with open(os.devnull, "w") as devnull:
         subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
+
+
+# -pi 1 (print_info, mcmc.c:1267-1316: progress text every update/100 iterations) and the empty-cluster restart
+# (check_empty_cluster mcmc.c:1944-1974; InStruct.c:185-190: the chain is discarded and re-run, the stream continuing):
+# name: (data file, CLI).  Both the result file and the program's STDOUT of the pure reference binary are kept.
+# ec1: N=8 L=300, two true clusters analysed with K=4: chain 2 trips the check at its 5th stored step and is re-run.
+STDOUT_CLI = {
+    "ec1": ("ec1.txt", ["-K", "4", "-L", "300", "-N", "8", "-p", "2", "-u", "400", "-b", "200", "-t", "10", "-c", "2", "-v", "2", "-g", "1",
+                        "-r", "5", "-j", "5", "-lb", "0", "-a", "0", "-s", "14", "4", "1972", "-pi", "1"]),
+    "pi_mode4": ("c1.txt", ["-K", "3", "-L", "100", "-N", "50", "-p", "2", "-u", "200", "-b", "100", "-t", "10", "-c", "1", "-v", "4", "-g", "1",
+                            "-r", "5", "-j", "5", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "1", "-e", "0"]),
+    "pi_mode3": ("c1.txt", ["-K", "3", "-L", "100", "-N", "50", "-p", "2", "-u", "100", "-b", "50", "-t", "10", "-c", "1", "-v", "3", "-f", "0",
+                            "-g", "1", "-r", "5", "-j", "5", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "1"]),
+    "pi_mode5": ("c1.txt", ["-K", "3", "-L", "100", "-N", "50", "-p", "2", "-u", "100", "-b", "50", "-t", "10", "-c", "1", "-v", "5", "-f", "0",
+                            "-g", "1", "-r", "5", "-j", "5", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "1"]),
+    "pi_tetra": ("t1.txt", ["-K", "3", "-L", "40", "-N", "60", "-p", "4", "-ap", "1", "-af", "1", "-u", "100", "-b", "50", "-t", "5", "-c", "1",
+                            "-v", "2", "-g", "1", "-r", "4", "-j", "4", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "1", "-e", "0"]),
+}
+
+
+def ec1_data():
+    return synth.raw_alleles(8, 300, 2, 2, 2, 0.0, 777)
 
 
 # K scan (-ik 1 -kv 2 3: InStruct.c:536-601 runs all chains for every K and keeps the K with the smallest DIC)

@@ -559,6 +559,47 @@ def test_reader_and_sampler_replaced_cli_output_equals_reference(tmp_path):
     assert body(str(out4)) == body(os.path.join(gu.GOLDEN, "t1_cli_output.txt"))
 
 
+def _stdout_equal(got, want):
+    """Program stdout, line by line.  print_info prints doubles at %f (mcmc.c:1275-1313): the device's doubles agree
+    with the reference's to ~1e-12 relative, so a printed 6th decimal may round the other way -- numbers are compared
+    within 2e-6, everything else byte for byte."""
+    import re
+    num = re.compile(rb"-?\d+\.\d{6}")
+    g, w = got.split(b"\n"), want.split(b"\n")
+    assert len(g) == len(w), (len(g), len(w))
+    for a, b in zip(g, w):
+        if a == b:
+            continue
+        assert num.sub(b"#", a) == num.sub(b"#", b), (a[:200], b[:200])
+        for x, y in zip(num.findall(a), num.findall(b)):
+            assert abs(float(x) - float(y)) <= 2e-6, (a[:200], b[:200])
+
+
+@pytest.mark.parametrize("name", sorted(gu.make_golden.STDOUT_CLI))
+def test_dropin_print_info_and_empty_cluster_restart_equal_reference(name, tmp_path):
+    """`-pi 1` (print_info, mcmc.c:1267-1316) for modes 2, 3, 4 (-e 0: states printed), 5 and ploidy 4, and -- case ec1
+    -- a chain that trips check_empty_cluster (mcmc.c:1944-1974) at its 5th stored step, is discarded and re-run with
+    the stream continuing (InStruct.c:185-190): the drop-in's STDOUT and result file equal the pure reference binary's
+    (tests/golden/<name>_cli_stdout.txt, _cli_output.txt)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "InStruct_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
+    data, cli = gu.make_golden.STDOUT_CLI[name]
+    out = tmp_path / "o.txt"
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, data), "-o", str(out)] + cli
+    log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+    assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
+    want = open(os.path.join(gu.GOLDEN, name + "_cli_stdout.txt"), "rb").read()
+    if name == "ec1":
+        assert want.count(b"has an empty cluster, thus discarded!") == 1 and want.count(b"Chain#2 Starts:") == 2
+    _stdout_equal(log.stdout, want)
+
+    def body(path):
+        return [l for l in open(path, "rb").read().split(b"\n")
+                if not (l.strip().startswith((b"Data File:", b"Output File:")) or b"InStruct" in l and b"-d" in l)]
+    assert body(str(out)) == body(os.path.join(gu.GOLDEN, name + "_cli_output.txt"))
+
+
 @pytest.fixture(scope="module")
 def full_size():
     geno, an, mi = synth.make_diploid(10000, 5000, 5)
