@@ -154,6 +154,12 @@ int isg_store_begin(isg_ctx *ctx, int with_freq);
 int isg_store_step(isg_ctx *ctx);
 int isg_store_fetch(isg_ctx *ctx, double *qq, double *qq2, double *indvlkh, double *gen, double *gen2, double *freq, double *freq2, long *steps);
 
+/* Replay-schedule update_ZQ runs as several cooperating workgroups that hand counts to each other by polling.  If such a
+ * sweep cannot complete (the GPU is shared and a workgroup was not scheduled in time, or a Dirichlet ran past the uniform
+ * budget) it is redone from the same stream position by the single-workgroup kernel: same results, only slower.  This
+ * returns how many sweeps of this context took that path (diagnostics; INSTRUCT_ZQ_TEST_ABORT=n forces the n-th one). */
+long isg_zq_fallbacks(isg_ctx *ctx);
+
 /* per-kernel device timing with HIP events on the launch stream (bench.py roofline) */
 int isg_profile_enable(isg_ctx *ctx, int on);
 int isg_profile_count(isg_ctx *ctx);

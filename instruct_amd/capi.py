@@ -24,7 +24,7 @@ EXPORTS = [
     "isg_get_alpha", "isg_get_totallkh", "isg_get_amax", "isg_set_z", "isg_set_freq", "isg_set_qq",
     "isg_set_generation", "isg_set_self_rates", "isg_set_alpha", "isg_keyed_layout", "isg_profile_enable",
     "isg_profile_count", "isg_profile_get", "isg_profile_reset", "isg_gelman_rubin", "isg_selftest",
-    "isg_store_begin", "isg_store_step", "isg_store_fetch",
+    "isg_store_begin", "isg_store_step", "isg_store_fetch", "isg_zq_fallbacks",
     "isg_ctx_create_poly", "isg_poly_update_geno", "isg_get_poly_geno", "isg_get_poly_gs", "isg_get_poly_table",
 ]
 
@@ -52,6 +52,8 @@ def load():
         lib.isg_set_seeds.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long]
         lib.isg_set_alpha.argtypes = [C.c_void_p, C.c_double]
         lib.isg_run.argtypes = [C.c_void_p, C.c_long]
+        lib.isg_zq_fallbacks.restype = C.c_long
+        lib.isg_zq_fallbacks.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -229,6 +231,10 @@ class HipChain:
         self._chk(self.lib.isg_store_fetch(self.h, *args, C.byref(steps)))
         out["steps"] = steps.value
         return out
+
+    def zq_fallbacks(self):
+        """replay update_ZQ sweeps that were redone by the single-workgroup kernel (see include/instruct_hip.h)"""
+        return self.lib.isg_zq_fallbacks(self.h)
 
     # --- profiling
     def profile(self, on=True):

@@ -142,6 +142,9 @@ struct isg_ctx {
 	int host_tape = 1;                    /* INSTRUCT_HOST_TAPE=0: the host loop steps the generator itself */
 	int spop_tree = 1;                    /* INSTRUCT_SPOP_TREE=0: the one-workgroup k_spop always */
 	size_t pipe_cap = 0;
+	double *d_qqsave = nullptr;           /* qq as it was when a cooperative update_ZQ started (it is both input and output) */
+	int test_abort = 0;                   /* INSTRUCT_ZQ_TEST_ABORT=n: the n-th cooperative sweep is treated as aborted (tests) */
+	long zq_fallbacks = 0;                /* sweeps redone by the single-workgroup kernel */
 	int *d_state;
 	double *d_ratios, *d_total;
 	std::vector<double> ratios_h;
@@ -353,7 +356,10 @@ __global__ void __launch_bounds__(BLOCK) k_gprop(DevView d, const double *S, isg
 			if (indiv) selfing = S[i];
 			else for (int k = 0; k < d.K; k++) selfing += d.qq[(size_t)i * d.K + k] * Ssh[k];
 			stat = isg_dt_stat(selfing);
-			if (stat < 0) { atomicOr(d.err, 2u); stat = 1; }
+			if (stat < 0) { /* mcmc.c:1540-1541: the reference prints the value and exits; the host does that after this launch */
+				if ((atomicOr(d.err, 2u) & 2u) == 0u) *(double *)(d.err + 2) = selfing; /* the first offender's value */
+				stat = 1;
+			}
 		}
 		unsigned flag = (i < d.N && stat == 1) ? 1u : 0u, tot, pre;
 		pre = block_excl_scan<BLOCK>(flag, sm, &tot);
@@ -2695,13 +2701,18 @@ static void prof_end(isg_ctx *c, const char *name)
 	c->prof_pending.push_back({name, c->prof_cur, e1});
 }
 
-static int check_dev_err(isg_ctx *c)
+/* the device error word, d_err[0] (bit 1: dt_stat saw a selfing rate outside [0,1], its value in d_err[2..3]); `e` was
+ * copied back by the caller together with whatever else it was waiting for */
+static int report_dev_err(const unsigned e[4])
 {
-	unsigned e = 0;
-	HIPCHK(hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
-	if (e & 2u) return fail("The value of selfing rate or inbreeding coefficient is beyond [0,1]!");
-	if (e) return fail("device error flag set");
+	if (e[0] & 2u) {
+		double v;
+		char msg[160];
+		memcpy(&v, e + 2, sizeof(v));
+		snprintf(msg, sizeof(msg), "The value of selfing rate or inbreeding coefficient %f is beyond [0,1]!", v); /* mcmc.c:1540 */
+		return fail(msg);
+	}
+	if (e[0]) return fail("device error flag set");
 	return 0;
 }
 
@@ -2956,9 +2967,12 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 		c->spop_tree = (e && atoi(e) == 0) ? 0 : 1;
 		e = getenv("INSTRUCT_ZQ_PIPE_XCD");
 		c->pipe_xcd = (e && atoi(e) == 0) ? 0 : 1;
+		e = getenv("INSTRUCT_ZQ_TEST_ABORT");
+		c->test_abort = e ? atoi(e) : 0;
 	}
 	DALLOC(d.cnt, int, (size_t)Lp * Amax * K);
 	DALLOC(d.qq, double, (size_t)N * K);
+	DALLOC(c->d_qqsave, double, (size_t)N * K);
 	DALLOC(d.qqnum, int, (size_t)N * K);
 	DALLOC(d.gen, int, N);
 	DALLOC(d.genprop, int, N);
@@ -2970,7 +2984,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	HIPCHK(hipMemcpy(dt, &c->tab_h, sizeof(isg_wh_tables), hipMemcpyHostToDevice));
 	d.tab = dt;
 	DALLOC(c->d_pos, uint64_t, 4);
-	DALLOC(c->d_err, unsigned, 1);
+	DALLOC(c->d_err, unsigned, 4);
 	DALLOC(c->d_S, double, ((cfg->mode == 3 || cfg->mode == 5) && N > ISG_KCAP) ? N : ISG_KCAP); /* modes 3, 5: one value per individual */
 	c->d_Fprop = nullptr;
 	if (cfg->mode == 5) { DALLOC(c->d_Fprop, double, N); }
@@ -3025,7 +3039,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	inbreed_free(c);
 	DevView &d = c->d;
 	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(d.lftab); (void)hipFree(d.lltab); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(c->d_pipe); (void)hipFree(c->d_spop); (void)hipFree(d.cnt);
-	(void)hipFree(d.qq); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
+	(void)hipFree(d.qq); (void)hipFree(c->d_qqsave); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
 	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S); (void)hipFree(c->d_Fprop); (void)hipFree(c->d_state); (void)hipFree(c->d_ratios); (void)hipFree(c->d_total);
 	prof_collect(c);
 	for (auto e : c->prof_free) (void)hipEventDestroy(e);
@@ -3121,9 +3135,12 @@ static int ensure_S(isg_ctx *c)
 static int ensure_lkh(isg_ctx *c)
 {
 	if (c->h_lkh) return 0;
+	unsigned e[4] = {0, 0, 0, 0};
 	HIPCHK(hipMemcpyAsync(c->indvlkh.data(), c->d.indvlkh, sizeof(double) * c->indvlkh.size(), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(&c->totallkh, c->d_total, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	if (!c->poly) HIPCHK(hipMemcpyAsync(e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	if (report_dev_err(e)) return 1;
 	c->h_lkh = true;
 	return 0;
 }
@@ -3275,14 +3292,37 @@ extern "C" int isg_update_G(isg_ctx *c)
 	c->h_gen = false;
 	if (!is_keyed(c)) {
 		uint64_t used = 0;
+		unsigned e[4] = {0, 0, 0, 0};
 		HIPCHK(hipMemcpyAsync(&used, c->d_pos, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipMemcpyAsync(e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream)); /* same wait: dt_stat out of range (mcmc.c:1524-1546) */
 		HIPCHK(hipStreamSynchronize(c->stream));
+		if (report_dev_err(e)) return 1;
 		host_advance(c, used);
 	}
-	return 0;
+	return 0; /* keyed schedule: no host wait here; the flag is read with the next likelihood download (ensure_lkh) */
 }
 
 /* ---- update_ZQ ---- */
+/* The cooperative replay kernels hand data between workgroups by polling, so every workgroup of the launch must be
+ * resident at the same time: `blocks` of `threads` threads have to fit on the device's CUs at this kernel's occupancy. */
+template <class Kern>
+static bool fits_resident(Kern kern, int threads, long blocks, int device)
+{
+	int per_cu = 0, cus = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0) != hipSuccess) return false;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
+	return (long)per_cu * cus >= blocks;
+}
+/* A cooperative sweep that did not complete (a hand-off timed out because the GPU is shared and a workgroup was not
+ * scheduled, or an individual's Dirichlet ran past the uniform tape) has overwritten part of Z, qq and qqnum.  Z and qqnum
+ * are outputs only; qq is restored from the copy taken before the launch and the sweep is redone from the same stream
+ * position by the single-workgroup kernel, which has no hand-offs and no tape budget -- same results, bit for bit. */
+static bool coop_sweep_failed(isg_ctx *c, const unsigned flags[2])
+{
+	bool bad = flags[0] || flags[1];
+	if (c->test_abort > 0 && --c->test_abort == 0) bad = true;
+	return bad;
+}
 template <int KMAX>
 static void launch_zq(isg_ctx *c, bool chain, isg_wh base, uint64_t pos0, uint64_t stride, int init_flag)
 {
@@ -3346,10 +3386,12 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 			}
 			HIPCHK(hipMemsetAsync(c->d_pipe, 0, need_words * sizeof(unsigned long long), c->stream));
 		}
+		HIPCHK(hipMemcpyAsync(c->d_qqsave, c->d.qq, sizeof(double) * (size_t)c->cfg.N * K, hipMemcpyDeviceToDevice, c->stream));
+		bool launched = true;
 		prof_begin(c);
-#define COOP_LAUNCH(KM) hipLaunchKernelGGL((k_zq_coop<KM>), dim3(pack ? 8 * G : G), dim3(256), 0, c->stream, c->d, base, init_flag, c->alpha, cb, c->d_pos, pack)
-#define SPEC_LAUNCH(KM) hipLaunchKernelGGL((k_zq_spec<KM>), dim3(pack ? 8 * G : G), dim3(256), 0, c->stream, c->d, base, c->alpha, cb, c->d_pos, pack)
-#define PIPE_LAUNCH(KM) hipLaunchKernelGGL((k_zq_pipe<KM, ISG_PIPE_DW>), dim3(ppack ? 8 * GP : GP), dim3(64 * (ISG_PIPE_DW + 1)), 0, c->stream, c->d, base, c->alpha, cb, c->d_pipe, c->d_pos, ppack)
+#define COOP_LAUNCH(KM) do { if (fits_resident(k_zq_coop<KM>, 256, G, c->cfg.device)) hipLaunchKernelGGL((k_zq_coop<KM>), dim3(pack ? 8 * G : G), dim3(256), 0, c->stream, c->d, base, init_flag, c->alpha, cb, c->d_pos, pack); else launched = false; } while (0)
+#define SPEC_LAUNCH(KM) do { if (fits_resident(k_zq_spec<KM>, 256, G, c->cfg.device)) hipLaunchKernelGGL((k_zq_spec<KM>), dim3(pack ? 8 * G : G), dim3(256), 0, c->stream, c->d, base, c->alpha, cb, c->d_pos, pack); else launched = false; } while (0)
+#define PIPE_LAUNCH(KM) do { if (fits_resident(k_zq_pipe<KM, ISG_PIPE_DW>, 64 * (ISG_PIPE_DW + 1), GP, c->cfg.device)) hipLaunchKernelGGL((k_zq_pipe<KM, ISG_PIPE_DW>), dim3(ppack ? 8 * GP : GP), dim3(64 * (ISG_PIPE_DW + 1)), 0, c->stream, c->d, base, c->alpha, cb, c->d_pipe, c->d_pos, ppack); else launched = false; } while (0)
 		if (pipe) {
 			switch (K) {
 			case 1: case 2: PIPE_LAUNCH(2); break;
@@ -3390,11 +3432,14 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 		HIPCHK(hipMemcpyAsync(&used, c->d_pos, sizeof(used), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipMemcpyAsync(flags, &cb->abort_flag, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
-		if (flags[0]) return fail("isg_update_ZQ: cooperative kernel aborted (a workgroup hand-off timed out)");
-		if (flags[1]) return fail("isg_update_ZQ: uniform tape exhausted (set INSTRUCT_ZQ_COOP=0)");
-		host_advance(c, used);
-		c->h_qq = false;
-		return 0;
+		if (launched && !coop_sweep_failed(c, flags)) {
+			host_advance(c, used);
+			c->h_qq = false;
+			return 0;
+		}
+		/* redo with the single-workgroup kernel below (see coop_sweep_failed) */
+		HIPCHK(hipMemcpyAsync(c->d.qq, c->d_qqsave, sizeof(double) * (size_t)c->cfg.N * K, hipMemcpyDeviceToDevice, c->stream));
+		c->zq_fallbacks++;
 	}
 	prof_begin(c);
 	switch (K) { /* small K: exact-size register arrays; larger K: rounded up */
@@ -3534,6 +3579,7 @@ extern "C" int isg_chain_init(isg_ctx *c, const float *initd)
 	const int N = c->cfg.N, K = c->cfg.K;
 	c->origin = c->rng;
 	c->iter = 0;
+	HIPCHK(hipMemsetAsync(c->d_err, 0, 4 * sizeof(unsigned), c->stream));
 	if (c->cfg.mode == 0) return isg_update_Z(c, 1); /* mcmc_POP_no_admixture does not draw alpha (no initial_chn) */
 	c->alpha = host_next(c) * 10;
 	if (c->cfg.mode == 2) {
@@ -3891,6 +3937,7 @@ extern "C" int isg_store_fetch(isg_ctx *c, double *qq, double *qq2, double *indv
 	return 0;
 }
 
+extern "C" long isg_zq_fallbacks(isg_ctx *c) { return c->zq_fallbacks; }
 extern "C" int isg_profile_enable(isg_ctx *c, int on) { c->prof = on != 0; return 0; }
 extern "C" int isg_profile_count(isg_ctx *c) { prof_collect(c); return (int)c->prof_entries.size(); }
 extern "C" int isg_profile_get(isg_ctx *c, int idx, char *name, int cap, double *ms, long *n)

@@ -330,6 +330,12 @@ void print_info(UPMCMC *p, SEQDATA data, int step, int maxstep) /* mcmc.c:1267-1
 }
 
 /* ------------------------------------------------------------------ the MI355X chain driver */
+/* A NaN of the reference run is always x86's default NaN -- sign bit set, printed "-nan" -- because it can only come from an
+ * invalid operation on finite inputs (inf - inf when a cluster's rate sits at exactly 0 or 1, ploidy 4 with -e 0) and is
+ * propagated unchanged from there.  The device's default NaN has the sign bit clear: give it the reference's sign before the
+ * host code prints it or folds it into the CHAIN means (print_info mcmc.c:1275, result_analysis.c:399-412). */
+static double ref_nan(double x) { return isnan(x) ? copysign(x, -1.0) : x; }
+
 static void hip_fail(const char *where)
 {
 	static char msg[512];
@@ -451,7 +457,8 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 		if (isg_iteration(ctx)) hip_fail("isg_iteration");
 		want_state = stored || data.print_iter == 1 || cnt_step == data.nstep_check_empty_cluster;
 		if (want_state) {
-			isg_get_totallkh(ctx, &node.totallkh);
+			if (isg_get_totallkh(ctx, &node.totallkh)) hip_fail("isg_get_totallkh");
+			node.totallkh = ref_nan(node.totallkh);
 			/* qq itself is only looked at by print_info and check_empty_cluster; its running means are kept on the device */
 			if (data.print_iter == 1 || cnt_step == data.nstep_check_empty_cluster || (stored && cnt_step + 1 == data.nstep_check_empty_cluster)) {
 				isg_get_qq(ctx, qqflat);
@@ -504,6 +511,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 		if (isg_store_fetch(ctx, q1, q2, mchain.indvlkh, with_gen ? mchain.gen : NULL, with_gen ? mchain.gen2 : NULL, with_freq ? freqflat : NULL, f2, &nst))
 			hip_fail("isg_store_fetch");
 		if (nst != mchain.step) nrerror("The number of steps stored on the device is not the same as counted");
+		for (i = 0; i < N; i++) mchain.indvlkh[i] = ref_nan(mchain.indvlkh[i]);
 		for (i = 0; i < N; i++)
 			for (k = 0; k < K; k++) {
 				mchain.qq[i][k] = q1[(size_t)i * K + k];
@@ -569,7 +577,10 @@ static CHAIN mcmc_hip_chain0(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	for (step = 0; step < initial.update; step++) {
 		const int stored = (step >= initial.burnin && (step + 1 - initial.burnin) % initial.thinning == 0);
 		if (isg_iteration(ctx)) hip_fail("isg_iteration");
-		if (stored || data.print_iter == 1) isg_get_totallkh(ctx, &node.totallkh);
+		if (stored || data.print_iter == 1) {
+			if (isg_get_totallkh(ctx, &node.totallkh)) hip_fail("isg_get_totallkh");
+			node.totallkh = ref_nan(node.totallkh);
+		}
 		if (data.print_iter == 1) print_info(&node, data, step, initial.update);
 		if (step == initial.burnin - 1) allocate_chn(&mchain, data);
 		if (stored) {

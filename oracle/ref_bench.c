@@ -26,7 +26,7 @@ int main(int argc, char **argv)
 	INIT ini;
 	CHAIN ch;
 	UPMCMC *ptr;
-	double **qqnum, t[7] = {0, 0, 0, 0, 0, 0, 0}, t0, t1, tinit;
+	double **qqnum, t[7] = {0, 0, 0, 0, 0, 0, 0}, t0, t1, tinit, tit, per[64];
 	int N, L, K, iters, i, j, k, it;
 	unsigned char *buf;
 	FILE *f, *devnull;
@@ -68,17 +68,21 @@ int main(int argc, char **argv)
 	update_ZQ(&ptr, d, 1, &qqnum);
 	tinit = now() - t0;
 	for (it = 0; it < iters; it++) {
+		tit = now();
 		t0 = now(); update_P(&ptr, d); t1 = now(); t[0] += t1 - t0;
 		t0 = t1; update_S_POP(d, &ptr); t1 = now(); t[1] += t1 - t0;
 		t0 = t1; update_G(d, &ptr); t1 = now(); t[2] += t1 - t0;
 		t0 = t1; update_ZQ(&ptr, d, 0, &qqnum); t1 = now(); t[3] += t1 - t0;
 		t0 = t1; update_alpha(&ptr, d, qqnum); t1 = now(); t[4] += t1 - t0;
 		t0 = t1; cal_lkh(&ptr, d); t1 = now(); t[5] += t1 - t0;
+		if (it < 64) per[it] = t1 - tit;
 	}
 	for (i = 0; i < 6; i++) t[6] += t[i];
 	fprintf(stderr, "{\"N\": %d, \"L\": %d, \"K\": %d, \"iters\": %d, \"init_s\": %.4f, \"s_per_iter\": %.6f, "
 		"\"update_P\": %.6f, \"update_S_POP\": %.6f, \"update_G\": %.6f, \"update_ZQ\": %.6f, \"update_alpha\": %.6f, \"cal_lkh\": %.6f, "
-		"\"totallkh\": %.6f}\n", N, L, K, iters, tinit, t[6] / iters, t[0] / iters, t[1] / iters, t[2] / iters, t[3] / iters,
+		"\"totallkh\": %.6f, \"per_iter_s\": [", N, L, K, iters, tinit, t[6] / iters, t[0] / iters, t[1] / iters, t[2] / iters, t[3] / iters,
 		t[4] / iters, t[5] / iters, ptr->totallkh);
+	for (it = 0; it < iters && it < 64; it++) fprintf(stderr, "%s%.6f", it ? ", " : "", per[it]);
+	fprintf(stderr, "]}\n");
 	return 0;
 }

@@ -65,3 +65,17 @@ def test_shim_object_compiles_against_the_abi():
     for sym in ("mcmc_updating", "free_chain", "chcksame", "genofreq_inbreedcoff", "dgeom", "print_info", "adpt_indp",
                 "hastings_stat", "dt_stat", "allocate_node", "free_node", "allocate_chn", "store_chn", "check_empty_cluster"):
         assert re.search(r"\bT %s\b" % sym, out), sym  # the exported surface of reference mcmc.h:56-69
+
+
+def test_fast_tetraploid_coder_equals_the_restatement_of_transform_data2():
+    """synth.code_tetraploid_fast builds every large ploidy-4 input (bench.py, the config-5 tests, the profiling tools);
+    synth.code_tetraploid restates transform_data2 (data_interface.c:571-669) and is what the golden cases are coded with"""
+    import numpy as np
+    from instruct_amd import synth
+    for (N, L, K, A, miss, seed) in ((40, 60, 3, 4, 0.05, 1), (25, 30, 2, 6, 0.2, 2), (12, 50, 4, 2, 0.0, 3), (9, 20, 3, 8, 0.5, 4)):
+        raw = synth.raw_alleles(N, L, K, 4, A, miss, seed)
+        if N == 9:
+            raw[:, 3, :] = synth.MISSING   # a locus nobody was typed at
+        a, b = synth.code_tetraploid(raw), synth.code_tetraploid_fast(raw)
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and np.array_equal(x, y)

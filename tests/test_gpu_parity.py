@@ -245,6 +245,44 @@ def test_replay_zq_kernel_variants_bit_exact_vs_canonical_oracle(case, env, monk
     h.close()
 
 
+@pytest.mark.parametrize("case", [(24, 700, 5, 0.05, 2), (8, 33000, 9, 0.0, 3)])
+def test_replay_zq_aborted_cooperative_sweep_is_redone_bit_exact(case, monkeypatch):
+    """INSTRUCT_ZQ_TEST_ABORT=2: the second cooperative update_ZQ sweep (= the first iteration's; the first is chain_init's)
+    is treated as aborted AFTER it ran, i.e. with Z, qq and qqnum overwritten -- what a timed-out hand-off on a shared GPU
+    leaves behind.  qq is restored from the copy taken before the launch, the single-workgroup kernel redoes the sweep from
+    the same stream position: state and stream position equal the oracle's, and the chain carries on."""
+    N, L, K, miss, nall = case
+    monkeypatch.setenv("INSTRUCT_ZQ_TEST_ABORT", "2")
+    geno, an, mi = synth.code_diploid(synth.raw_alleles(N, L, K, 2, nall, miss, 23))
+    h, o, initd = _pair(geno, an, mi, K, capi.SCHED_REPLAY)
+    h.chain_init(initd)
+    o.chain_init(initd)
+    assert h.zq_fallbacks() == 0
+    for it in range(3):
+        h.iteration()
+        o.iteration()
+        _same(h, o, ["z", "qq", "qqnum", "generation", "alpha", "self_rates", "freq", "indvlkh", "totallkh", "seeds"], it)
+        assert h.zq_fallbacks() == 1
+    h.close()
+
+
+def test_selfing_rate_out_of_range_is_reported_like_the_reference():
+    """dt_stat (mcmc.c:1524-1546) prints 'ERROR: The value of selfing rate or inbreeding coefficient %f is beyond [0,1]!' and
+    exits when qq . S leaves [0,1]; update_G on the device raises the same message through the ABI instead of sampling on."""
+    geno, an, mi = synth.code_diploid(synth.raw_alleles(30, 80, 3, 2, 2, 0.0, 3))
+    for sched in (capi.SCHED_REPLAY, capi.SCHED_KEYED):
+        h = capi.HipChain(geno, an, mi, 3, rng_sched=sched)
+        h.setseeds(13, 4, 1972)
+        h.chain_init(np.array([h.ran1() for _ in range(3)], dtype=np.float32))
+        h.iteration()
+        h.set_self_rates(np.array([1.5, 1.5, 1.5]))
+        with pytest.raises(capi.IsgError, match=r"selfing rate or inbreeding coefficient 1\.500000 is beyond \[0,1\]"):
+            h.update_G()
+            h.cal_lkh()
+            h.totallkh()   # keyed schedule: the flag comes back with the next likelihood download
+        h.close()
+
+
 @pytest.mark.parametrize("sched", [capi.SCHED_REPLAY, capi.SCHED_KEYED])
 @pytest.mark.parametrize("mode", [2, 4])
 def test_long_run_stays_bit_exact(mode, sched):

@@ -119,6 +119,14 @@ def test_tetraploid_single_workgroup_zq_kernel_gives_the_same_lines(monkeypatch)
     assert hip_lines("t1") == coop
 
 
+def test_tetraploid_aborted_cooperative_sweep_is_redone_bit_exact(monkeypatch):
+    """INSTRUCT_ZQ_TEST_ABORT=2: the first iteration's cooperative update_ZQ is treated as aborted after it ran; qq is
+    restored and the single-workgroup kernel redoes the sweep -- every later dump line unchanged"""
+    want = hip_lines("t1")
+    monkeypatch.setenv("INSTRUCT_ZQ_TEST_ABORT", "2")
+    assert hip_lines("t1") == want
+
+
 def _noseeds(line):
     return line.split(" seeds=")[0]
 
