@@ -159,6 +159,11 @@ int isg_store_fetch(isg_ctx *ctx, double *qq, double *qq2, double *indvlkh, doub
  * budget) it is redone from the same stream position by the single-workgroup kernel: same results, only slower.  This
  * returns how many sweeps of this context took that path (diagnostics; INSTRUCT_ZQ_TEST_ABORT=n forces the n-th one). */
 long isg_zq_fallbacks(isg_ctx *ctx);
+/* Replay-schedule update_ZQ (K <= 8) first RESOLVES the start position of every individual, a block of individuals per
+ * launch on the whole chip, then runs the sweep as one parallel pass (instruct_amd/csrc/isg_resolve_hip.inc;
+ * INSTRUCT_ZQ_RESOLVE=0 selects the chain kernels).  Diagnostics of the last sweep:
+ * out = {blocks, blocks ended early by a window miss, kernel launches, individuals per block, units per block, 1000 mu} */
+int isg_zq_resolve_stats(isg_ctx *ctx, long out[6]);
 
 /* per-kernel device timing with HIP events on the launch stream (bench.py roofline) */
 int isg_profile_enable(isg_ctx *ctx, int on);

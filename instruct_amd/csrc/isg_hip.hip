@@ -94,8 +94,10 @@ struct ProfPending {
 
 struct PolyCtx;
 struct InbreedCtx;
+struct ResolveCtx;
 struct isg_ctx {
 	isg_config cfg;
+	ResolveCtx *rs = nullptr; /* replay update_ZQ: start positions resolved block-wise (isg_resolve_hip.inc) */
 	PolyCtx *poly = nullptr; /* ploidy 4 state (isg_poly_hip.inc) */
 	InbreedCtx *inb = nullptr; /* mode 4 state (isg_modes_hip.inc) */
 	DevView d;
@@ -1654,19 +1656,20 @@ __global__ void __launch_bounds__(256) k_zq_coop(DevView d, isg_wh base, int ini
  * barrier.  Walks that leave the table (1 % at K = 5) are redone sequentially by lane 0 of each wave.
  * Counts: sh.hist3[buf] + sh.ghist3[buf]; the caller's barrier made them complete.
  */
-template <int KMAX>
-__device__ __forceinline__ unsigned dirichlet_wave(const DevView &d, ZqShared &sh, int i, const isg_wh &cur, unsigned long long dstart_off,
-						  double alpha, int buf, const double *dtape, bool writer, bool pre = false, double ppu0 = 0.0, double ppu1 = 0.0)
+/* cntf(m) = the individual's count of cluster m; tab = the skip-ahead tables (LDS) */
+template <int KMAX, class CntF>
+__device__ __forceinline__ unsigned dirichlet_wave_f(const DevView &d, const isg_wh_tables *tab, CntF cntf, int i, const isg_wh &cur, unsigned long long dstart_off,
+						    double alpha, const double *dtape, bool writer, bool pre = false, double ppu0 = 0.0, double ppu1 = 0.0)
 {
 	const int K = d.K, lane = (int)lane_id(), D = 64 / K;
 	const int m = (lane < K * D) ? lane / D : K - 1, dd = lane - m * D;
 	const bool act = lane < K * D;
-	const int cnt = sh.hist3[buf][m] + sh.ghist3[buf][m];
+	const int cnt = cntf(m);
 	const double a = (double)cnt + alpha;
 	isg_cursor c;
 	c.used = 0;
 	c.tape = dtape ? dtape + 2 * (m + dd) : nullptr;
-	if (!dtape) c.s = isg_wh_jump(&sh.tab, cur, dstart_off + 2ull * (unsigned)(m + dd));
+	if (!dtape) c.s = isg_wh_jump(tab, cur, dstart_off + 2ull * (unsigned)(m + dd));
 	double r = -1;
 	if (act) {
 		double pu0, pu1;
@@ -1737,9 +1740,9 @@ __device__ __forceinline__ unsigned dirichlet_wave(const DevView &d, ZqShared &s
 			isg_cursor q;
 			q.used = 0;
 			q.tape = nullptr;
-			q.s = isg_wh_jump(&sh.tab, cur, dstart_off);
+			q.s = isg_wh_jump(tab, cur, dstart_off);
 #pragma unroll
-			for (int mm = 0; mm < KMAX; mm++) g[mm] = (mm < K) ? isg_rgamma(&q, (double)(sh.hist3[buf][mm] + sh.ghist3[buf][mm]) + alpha) : 0.0;
+			for (int mm = 0; mm < KMAX; mm++) g[mm] = (mm < K) ? isg_rgamma(&q, (double)cntf(mm) + alpha) : 0.0;
 			u = q.used;
 		} else {
 #pragma unroll
@@ -1757,10 +1760,16 @@ __device__ __forceinline__ unsigned dirichlet_wave(const DevView &d, ZqShared &s
 		for (int k2 = 0; k2 < K; k2++) sum += readlane_f64(v, k2);
 		if (lane < K) {
 			d.qq[(size_t)i * K + lane] = v / sum;
-			d.qqnum[(size_t)i * K + lane] = sh.hist3[buf][lane] + sh.ghist3[buf][lane];
+			d.qqnum[(size_t)i * K + lane] = cntf(lane);
 		}
 	}
 	return used;
+}
+template <int KMAX>
+__device__ __forceinline__ unsigned dirichlet_wave(const DevView &d, ZqShared &sh, int i, const isg_wh &cur, unsigned long long dstart_off,
+						  double alpha, int buf, const double *dtape, bool writer, bool pre = false, double ppu0 = 0.0, double ppu1 = 0.0)
+{
+	return dirichlet_wave_f<KMAX>(d, &sh.tab, [&](int m) { return sh.hist3[buf][m] + sh.ghist3[buf][m]; }, i, cur, dstart_off, alpha, dtape, writer, pre, ppu0, ppu1);
 }
 
 /*
@@ -2839,6 +2848,8 @@ static void host_tape_end(isg_ctx *c, isg_cursor *cur)
 
 extern "C" const char *isg_last_error(void) { return g_err.c_str(); }
 
+#include "isg_resolve_hip.inc"
+
 /* ploidy 4 (isg_poly_hip.inc, included further down) */
 static int poly_ctx_create(const isg_config *cfg, const int32_t *allelenum, const int32_t *seq, isg_ctx **out);
 static void poly_ctx_destroy(isg_ctx *c);
@@ -2933,6 +2944,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	c->tape_cap = 0;
 	c->nvalid_total = 0;
 	for (int i = 0; i < N; i++) c->nvalid_total += (uint64_t)nvalid[i];
+	if (resolve_alloc(c, nvalid)) return 1;
 	{
 		const int nwv = (Lp + 63) / 64 + 1;
 		std::vector<unsigned> rw((size_t)N * nwv, 0);
@@ -3028,6 +3040,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	(void)hipSetDevice(c->cfg.device);
 	(void)hipStreamSynchronize(c->stream);
 	store_free(c);
+	resolve_free(c);
 	if (c->poly) {
 		poly_ctx_destroy(c);
 		prof_collect(c);
@@ -3343,6 +3356,11 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 	uint64_t stride = c->ky[KY_SZ];
 	c->d.tape = nullptr;
 	c->d.tape_len = 0;
+	if (chain && !init_flag && c->rs) { /* the start positions resolved block-wise, then one parallel sweep (isg_resolve_hip.inc) */
+		bool done = false;
+		if (resolve_update_ZQ(c, base, &done)) return 1;
+		if (done) return 0;
+	}
 	if (chain) {
 		/* replay schedule: the phase consumes a contiguous run of the stream (2 uniforms per used
 		 * locus, plus each individual's Dirichlet).  Its uniforms do not depend on where the

@@ -224,12 +224,16 @@ def test_edge_shapes_bit_exact_vs_canonical_oracle(case, sched):
 
 # replay update_ZQ kernel variants: the default picks k_zq_pipe (K <= 8, one locus per lane, Lp < 32768), k_zq_spec or
 # k_zq_coop; the environment switches force the other ones; all of them must give the oracle's state
-@pytest.mark.parametrize("env", [{}, {"INSTRUCT_ZQ_PIPE": "0"}, {"INSTRUCT_ZQ_SPEC": "0"}, {"INSTRUCT_ZQ_XCD": "1"},
-                                 {"INSTRUCT_ZQ_SPEC": "0", "INSTRUCT_ZQ_XCD": "1"}, {"INSTRUCT_ZQ_COOP": "0"}])
+_R0 = {"INSTRUCT_ZQ_RESOLVE": "0"}   # the chain kernels (the default resolves the start positions block-wise first)
+@pytest.mark.parametrize("env", [{}, {"INSTRUCT_ZQ_RESOLVE_UNITS": "16"}, {"INSTRUCT_ZQ_RESOLVE_A": "0.6"}, _R0, dict(_R0, INSTRUCT_ZQ_PIPE="0"),
+                                 dict(_R0, INSTRUCT_ZQ_PIPE_XCD="0"), dict(_R0, INSTRUCT_ZQ_SPEC="0"), dict(_R0, INSTRUCT_ZQ_XCD="1"),
+                                 dict(_R0, INSTRUCT_ZQ_SPEC="0", INSTRUCT_ZQ_XCD="1"), dict(_R0, INSTRUCT_ZQ_COOP="0")])
 @pytest.mark.parametrize("case", [(24, 700, 5, 0.05, 2), (6, 40000, 3, 0.02, 2), (8, 33000, 9, 0.0, 3),
                                   (10, 20000, 8, 0.03, 3), (16, 3000, 2, 0.1, 2)])
 def test_replay_zq_kernel_variants_bit_exact_vs_canonical_oracle(case, env, monkeypatch):
-    """L > 32768: more loci than 128 workgroups x 256 lanes -> several passes per individual in the cooperative kernels"""
+    """L > 32768: more loci than 128 workgroups x 256 lanes -> several passes per individual in the cooperative kernels.
+    INSTRUCT_ZQ_RESOLVE_UNITS=16: blocks of a few individuals; INSTRUCT_ZQ_RESOLVE_A=0.6: windows so narrow that most
+    blocks end early on a miss"""
     N, L, K, miss, nall = case
     for k, v in env.items():
         monkeypatch.setenv(k, v)
