@@ -162,8 +162,9 @@ long isg_zq_fallbacks(isg_ctx *ctx);
 /* Replay-schedule update_ZQ (K <= 8) first RESOLVES the start position of every individual, a block of individuals per
  * launch on the whole chip, then runs the sweep as one parallel pass (instruct_amd/csrc/isg_resolve_hip.inc;
  * INSTRUCT_ZQ_RESOLVE=0 selects the chain kernels).  Diagnostics of the last sweep:
- * out = {blocks, blocks ended early by a window miss, kernel launches, individuals per block, units per block, 1000 mu} */
-int isg_zq_resolve_stats(isg_ctx *ctx, long out[6]);
+ * out = {blocks, blocks ended early by a window miss, kernel launches, individuals per block, units per block, 1000 mu,
+ * 1000 sigma, draws redone exactly (diagnostic builds)} */
+int isg_zq_resolve_stats(isg_ctx *ctx, long out[8]);
 
 /* per-kernel device timing with HIP events on the launch stream (bench.py roofline) */
 int isg_profile_enable(isg_ctx *ctx, int on);

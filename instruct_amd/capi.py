@@ -237,9 +237,9 @@ class HipChain:
         return self.lib.isg_zq_fallbacks(self.h)
 
     def zq_resolve_stats(self):
-        out = (C.c_long * 6)()
+        out = (C.c_long * 8)()
         self._chk(self.lib.isg_zq_resolve_stats(self.h, out))
-        return dict(zip(("blocks", "misses", "launches", "D", "units", "mu_x1000"), out))
+        return dict(zip(("blocks", "misses", "launches", "D", "units", "mu_x1000", "sigma_x1000", "exact_redone"), out))
 
     # --- profiling
     def profile(self, on=True):

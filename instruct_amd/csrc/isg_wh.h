@@ -122,10 +122,27 @@ ISG_HD double isg_wh_next(isg_wh *s)
 	return isg_wh_value(s);
 }
 
+/* n mod m for n < 2^52 and a small constant m, without a 64-bit integer division (which a GPU lane emulates in a few
+ * hundred instructions): quotient estimate in double (off by at most one), exact remainder by fma, one correction
+ * either way.  Stream positions stay far below 2^52 (the generator's period is 6.95e12). */
+ISG_HD uint32_t isg_mod_u64(uint64_t n, uint32_t m)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const double x = (double)n, md = (double)m;
+	const double q = __builtin_floor(x * (1.0 / md));
+	double r = isg_fma(-q, md, x);
+	r = (r < 0.0) ? r + md : r;
+	r = (r >= md) ? r - md : r;
+	return (uint32_t)r;
+#else
+	return (uint32_t)(n % m);
+#endif
+}
+
 /* state n draws after `s` (n = 0 returns s itself, reduced) */
 ISG_HD isg_wh isg_wh_jump(const isg_wh_tables *t, isg_wh s, uint64_t n)
 {
-	uint32_t e1 = (uint32_t)(n % (ISG_M1 - 1)), e2 = (uint32_t)(n % (ISG_M2 - 1)), e3 = (uint32_t)(n % (ISG_M3 - 1));
+	uint32_t e1 = isg_mod_u64(n, ISG_M1 - 1), e2 = isg_mod_u64(n, ISG_M2 - 1), e3 = isg_mod_u64(n, ISG_M3 - 1);
 	uint32_t p1 = (uint32_t)t->lo[0][e1 & 255] * t->hi[0][e1 >> 8] % ISG_M1;
 	uint32_t p2 = (uint32_t)t->lo[1][e2 & 255] * t->hi[1][e2 >> 8] % ISG_M2;
 	uint32_t p3 = (uint32_t)t->lo[2][e3 & 255] * t->hi[2][e3 >> 8] % ISG_M3;
