@@ -176,8 +176,13 @@ int isg_profile_reset(isg_ctx *ctx);
  * quotient by reciprocal + fma, table skip-ahead) against the plain formulas of random.c:19-47 */
 int isg_selftest(void);
 
-/* one-shot exchange of the per-chain log-likelihood samples for the Gelman-Rubin check
- * (CONVG.convg_ld, mcmc.c:223-224; check_converg.c:100-153): see instruct_amd/host */
+/* Chains sharded one per GPU (the reference runs them back to back, InStruct.c:182-193): the only exchange is each chain's
+ * n stored log-likelihood samples (CONVG.convg_ld, mcmc.c:223-224).  isg_gather_convg: ONE ncclAllGather over RCCL / xGMI
+ * on device buffers; all[r * n + k] = sample k of rank r.  id_path: a file every rank can reach (rank 0 publishes the
+ * ncclUniqueId there).  Called by instruct_amd/host/mcmc_hip.c when instruct_amd/host/instruct_mgpu.c launched it.
+ * isg_gelman_rubin: GelmanRubin (check_converg.c:100-153) on the gathered vector, including the reference's indexing
+ * (repperchain = totrep / numchains, check_converg.c:121-137). */
+int isg_gather_convg(isg_ctx *ctx, int rank, int world, const char *id_path, const double *mine, int n, double *all);
 double isg_gelman_rubin(const double *vec, int numchains, int totrep);
 
 #ifdef __cplusplus

@@ -59,6 +59,10 @@ def build_host(force=False):
     robj = os.path.join(HOST, "data_interface_stream.o")
     if force or _newer(robj, [rsrc, os.path.join(HOST, "instruct_types.h")]):
         _run(["gcc", "-O2", "-fPIC", "-Wall", "-c", rsrc, "-o", robj])
+    # the multi-GPU launcher (plain C, no GPU call of its own)
+    msrc, mexe = os.path.join(HOST, "instruct_mgpu.c"), os.path.join(HOST, "instruct_mgpu")
+    if force or _newer(mexe, [msrc]):
+        _run(["gcc", "-O2", "-Wall", msrc, "-o", mexe, "-lm"])
     return obj
 
 

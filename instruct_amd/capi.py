@@ -24,7 +24,7 @@ EXPORTS = [
     "isg_get_alpha", "isg_get_totallkh", "isg_get_amax", "isg_set_z", "isg_set_freq", "isg_set_qq",
     "isg_set_generation", "isg_set_self_rates", "isg_set_alpha", "isg_keyed_layout", "isg_profile_enable",
     "isg_profile_count", "isg_profile_get", "isg_profile_reset", "isg_gelman_rubin", "isg_selftest",
-    "isg_store_begin", "isg_store_step", "isg_store_fetch", "isg_zq_fallbacks", "isg_zq_resolve_stats",
+    "isg_store_begin", "isg_store_step", "isg_store_fetch", "isg_zq_fallbacks", "isg_zq_resolve_stats", "isg_gather_convg",
     "isg_ctx_create_poly", "isg_poly_update_geno", "isg_get_poly_geno", "isg_get_poly_gs", "isg_get_poly_table",
 ]
 
@@ -235,6 +235,13 @@ class HipChain:
     def zq_fallbacks(self):
         """replay update_ZQ sweeps that were redone by the single-workgroup kernel (see include/instruct_hip.h)"""
         return self.lib.isg_zq_fallbacks(self.h)
+
+    def gather_convg(self, rank, world, id_path, mine):
+        """ncclAllGather of this chain's log-likelihood samples (RCCL on device buffers) -> [world * n]"""
+        mine = np.ascontiguousarray(mine, dtype=np.float64)
+        out = np.empty(world * mine.size, dtype=np.float64)
+        self._chk(self.lib.isg_gather_convg(self.h, rank, world, str(id_path).encode(), _ptr(mine), mine.size, _ptr(out)))
+        return out
 
     def zq_resolve_stats(self):
         out = (C.c_long * 8)()

@@ -3995,6 +3995,8 @@ extern "C" int isg_selftest(void)
 	return 0;
 }
 
+#include "isg_rccl.inc"
+
 /* ---- Gelman-Rubin on the gathered log-likelihood samples (check_converg.c:100-153) ---- */
 extern "C" double isg_gelman_rubin(const double *vec, int numchains, int totrep)
 {

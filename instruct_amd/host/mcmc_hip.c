@@ -13,6 +13,8 @@
  * reference run.
  *
  * Environment: INSTRUCT_GPU_RNG=replay|keyed (default replay), INSTRUCT_DEVICE=<ordinal>.
+ * Set by the multi-GPU launcher (instruct_mgpu.c), one process per chain: INSTRUCT_MGPU_RANK, INSTRUCT_MGPU_WORLD,
+ * INSTRUCT_MGPU_DIR (rendezvous directory), INSTRUCT_MGPU_GATHER=rccl|file -- see mgpu_exchange() below.
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -355,6 +357,46 @@ static void read_host_seeds(long s[3]) /* the host program's random.c keeps its 
 	free(buf);
 }
 
+/*
+ * One chain per process and GPU (instruct_mgpu.c): the chain's stored log-likelihood samples (CONVG.convg_ld of chain 0,
+ * mcmc.c:223-224) are what the Gelman-Rubin check needs from every chain (check_converg.c:44-91).  Each rank leaves its
+ * samples as raw doubles in <dir>/convg.<rank>.bin; with INSTRUCT_MGPU_GATHER=rccl the ranks also exchange them with one
+ * ncclAllGather over RCCL / xGMI (isg_gather_convg) and rank 0 leaves the gathered vector in <dir>/convg_all.bin.  The
+ * launcher evaluates the statistic and assembles the result file.  A chain discarded for an empty cluster
+ * (InStruct.c:185-190) does not take part: its re-run does.
+ */
+static void mgpu_exchange(isg_ctx *ctx, const CONVG *cvg, int chn)
+{
+	const char *er = getenv("INSTRUCT_MGPU_RANK"), *ew = getenv("INSTRUCT_MGPU_WORLD"), *dir = getenv("INSTRUCT_MGPU_DIR"), *eg = getenv("INSTRUCT_MGPU_GATHER");
+	char path[4096];
+	const double *mine;
+	int rank, world, n;
+	FILE *f;
+	if (!er || !ew || !dir || cvg == NULL) return;
+	rank = atoi(er);
+	world = atoi(ew);
+	n = cvg->ckrep;
+	mine = cvg->convg_ld + (size_t)chn * n;
+	snprintf(path, sizeof(path), "%s/convg.%d.bin", dir, rank);
+	if ((f = fopen(path, "wb")) == NULL || fwrite(mine, sizeof(double), (size_t)n, f) != (size_t)n) nrerror("cannot write the log-likelihood samples for the multi-GPU launcher");
+	fclose(f);
+	if (eg && strcmp(eg, "rccl") == 0) {
+		double *all = (double *)malloc(sizeof(double) * (size_t)n * world);
+		if (!all) nrerror("allocation failure in mgpu_exchange");
+		snprintf(path, sizeof(path), "%s/nccl_id", dir);
+		if (isg_gather_convg(ctx, rank, world, path, mine, n, all)) hip_fail("isg_gather_convg");
+		if (rank == 0) {
+			char tmp[4200];
+			snprintf(path, sizeof(path), "%s/convg_all.bin", dir);
+			snprintf(tmp, sizeof(tmp), "%s.tmp", path);
+			if ((f = fopen(tmp, "wb")) == NULL || fwrite(all, sizeof(double), (size_t)n * world, f) != (size_t)n * world) nrerror("cannot write the gathered log-likelihood samples");
+			fclose(f);
+			if (rename(tmp, path) != 0) nrerror("cannot publish the gathered log-likelihood samples");
+		}
+		free(all);
+	}
+}
+
 /* one cached device context per process: the driver runs chains back to back on the same data */
 static isg_ctx *g_ctx;
 static int ***g_ctx_key;
@@ -503,6 +545,7 @@ static CHAIN mcmc_hip_chain(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	}
 	isg_get_seeds(ctx, seeds);
 	setseeds((int)seeds[0], (int)seeds[1], (int)seeds[2]);
+	if (mchain.flag_empty_cluster == 0) mgpu_exchange(ctx, cvg, chn);
 	if (stored_on_device) { /* the running means come back once, into the CHAIN the caller will read */
 		const int with_gen = has_gen(data), with_freq = (data.print_freq == 1 && !tetra);
 		double *q1 = (double *)malloc(sizeof(double) * (size_t)N * K), *q2 = (double *)malloc(sizeof(double) * (size_t)N * K);
@@ -599,6 +642,7 @@ static CHAIN mcmc_hip_chain0(SEQDATA data, INIT initial, int chn, CONVG *cvg)
 	}
 	isg_get_seeds(ctx, seeds);
 	setseeds((int)seeds[0], (int)seeds[1], (int)seeds[2]);
+	mgpu_exchange(ctx, cvg, chn);
 	free_ivector(node.zz, 0, N - 1);
 	free_dvector(node.indvlkh, 0, N - 1);
 	if (data.print_freq == 1) free_d3tensor(node.freq, 0, K - 1, 0, L - 1, 0, A - 1);

@@ -111,6 +111,13 @@ def main():
     cmd = [CLI_REF, "-d", "c1.txt", "-o", "c1_mode0_cli_output.txt"] + MODE0_CLI
     with open(os.devnull, "w") as devnull:
         subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
+    for r in range(2):
+        outp = "mgpu_rank%d_cli_output.txt" % r
+        if os.path.exists(os.path.join(HERE, outp)):
+            os.unlink(os.path.join(HERE, outp))
+        cmd = [CLI_REF, "-d", "c1.txt", "-o", outp, "-cf", "mgpu_rank%d_cf.txt" % r] + mgpu_rank_cli(r)
+        with open(os.devnull, "w") as devnull:
+            subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
     synth.write_text_diploid(os.path.join(HERE, "ec1.txt"), ec1_data())
     for name, (data, cli) in STDOUT_CLI.items():
         if os.path.exists(os.path.join(HERE, name + "_cli_output.txt")):
@@ -140,6 +147,17 @@ STDOUT_CLI = {
     "pi_tetra": ("t1.txt", ["-K", "3", "-L", "40", "-N", "60", "-p", "4", "-ap", "1", "-af", "1", "-u", "100", "-b", "50", "-t", "5", "-c", "1",
                             "-v", "2", "-g", "1", "-r", "4", "-j", "4", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "1", "-e", "0"]),
 }
+
+
+# multi-GPU launcher (instruct_amd/host/instruct_mgpu.c): chain r of a sharded run = a separate `-c 1 -s s1+r s2+r s3+r` run.
+# The pure reference binary's result file and -cf dump (log-likelihood samples at %f) for ranks 0 and 1:
+MGPU_BASE = ["-K", "3", "-L", "100", "-N", "50", "-p", "2", "-u", "120", "-b", "60", "-t", "10", "-v", "2", "-r", "6", "-j", "5",
+             "-lb", "0", "-a", "0", "-pi", "0"]
+MGPU_SEEDS = (21, 7, 1999)
+
+
+def mgpu_rank_cli(r):
+    return MGPU_BASE + ["-c", "1", "-g", "1", "-s"] + [str(x + r) for x in MGPU_SEEDS]
 
 
 def ec1_data():
