@@ -160,6 +160,52 @@ ISG_HD int isg_poly_cat(const int *g)
 	for (i = 0; i < 4; i++) c0 += (g[i] == tmp[0]);
 	return c0 == 2 ? 2 : 1;
 }
+
+/*
+ * Allotetraploid (-ap 0): a genotype is a pair of diploid genotypes, one per subgenome -- copies 0, 1 from the first
+ * (allele frequencies freq), copies 2, 3 from the second (freq2).  Four classes for a locus with n alleles, in table order
+ * (allo_geno_num / allo_geno_list, poly_geno.c:2031-2119):  0 iikk (both homozygous), 1 iikl (second heterozygous),
+ * 2 ijkk (first heterozygous), 3 ijkl (both).  A canonical genotype (g0 <= g1, g2 <= g3) has a closed-form row:
+ * with C = n (n - 1) / 2 and pair(a, b) = the rank of a < b among the pairs in lexicographic order,
+ *   iikk  g0 n + g2 | iikl  n^2 + g0 C + pair(g2, g3) | ijkk  n^2 + n C + pair(g0, g1) n + g2 | ijkl  n^2 + 2 n C + pair(g0, g1) C + pair(g2, g3)
+ * -- the reference finds rows by linear search of the base-n code (find_id, poly_geno.c:2367-2381); same rows.
+ */
+ISG_HD int isg_allo_G(int n) { return n * n + n * (n - 1) * n + n * (n - 1) * n * (n - 1) / 4; }
+ISG_HD int isg_allo_pair(int a, int b, int n) { return a * n - a * (a + 1) / 2 + (b - a - 1); } /* a < b */
+ISG_HD int isg_allo_row(int n, int g0, int g1, int g2, int g3) /* canonical genotype -> table row */
+{
+	const int C = n * (n - 1) / 2, hetA = g0 != g1, hetB = g2 != g3;
+	if (!hetA && !hetB) return g0 * n + g2;
+	if (!hetA) return n * n + g0 * C + isg_allo_pair(g2, g3, n);
+	if (!hetB) return n * n + n * C + isg_allo_pair(g0, g1, n) * n + g2;
+	return n * n + 2 * n * C + isg_allo_pair(g0, g1, n) * C + isg_allo_pair(g2, g3, n);
+}
+ISG_HD int isg_allo_row_any(int n, int a, int b, int c, int d) /* each pair in either order */
+{
+	return isg_allo_row(n, a < b ? a : b, a < b ? b : a, c < d ? c : d, c < d ? d : c);
+}
+/* get_cat_allo (poly_geno.c:1341-1372) */
+ISG_HD int isg_allo_cat(const int *g) { return (g[0] != g[1] ? 2 : 0) + (g[2] != g[3] ? 1 : 0); }
+/* class sizes and the base-n codes in table order (g[1..4]; g[5] = 0) */
+static inline void isg_allo_build(int n, int g[6], int *list)
+{
+	int a, b, c, d, r = 0;
+	const int C = n * (n - 1) / 2;
+	g[1] = n * n; g[2] = n * C; g[3] = n * C; g[4] = C * C; g[5] = 0;
+	g[0] = isg_allo_G(n);
+	for (a = 0; a < n; a++)
+		for (c = 0; c < n; c++) list[r++] = ((a * n + a) * n + c) * n + c;
+	for (a = 0; a < n; a++)
+		for (c = 0; c < n - 1; c++)
+			for (d = c + 1; d < n; d++) list[r++] = ((a * n + a) * n + c) * n + d;
+	for (a = 0; a < n - 1; a++)
+		for (b = a + 1; b < n; b++)
+			for (c = 0; c < n; c++) list[r++] = ((a * n + b) * n + c) * n + c;
+	for (a = 0; a < n - 1; a++)
+		for (b = a + 1; b < n; b++)
+			for (c = 0; c < n - 1; c++)
+				for (d = c + 1; d < n; d++) list[r++] = ((a * n + b) * n + c) * n + d;
+}
 #endif /* ISG_POLY_COMMON */
 
 /* ---- instantiated part: needs PT_NAME, PT_LOG, PT_EXP ---- */
@@ -318,5 +364,68 @@ ISG_HD void PT_NAME(genfreq_row)(float self, const isg_polyclass *pc, const floa
 			}
 		fr[i] = (float)(PT_LOG((1 - self) * PT_EXP((double)ex[i]) + temp) - PT_LOG((double)(1 - self)));
 		if (fr[i] > 0) *err |= 4;
+	}
+}
+
+/* calc_exfreq_allo (poly_geno.c:1592-1670) for one (cluster, locus): f / f2 = the cluster's allele frequencies in the two
+ * subgenomes.  Copies 0, 1 (digits 3, 2 of the code) take f, copies 2, 3 take f2; float / double exactly as the reference. */
+ISG_HD void PT_NAME(exfreq_row_allo)(const isg_polyclass *pc, const double *f, const double *f2, float *ex)
+{
+	const int n = pc->n;
+	int r;
+	for (r = 0; r < pc->G; r++) {
+		const int code = pc->list[r], d0 = code % n, d1 = (code / n) % n, d2 = (code / n / n) % n, d3 = code / n / n / n;
+		if (r < pc->g[1]) ex[r] = (float)((PT_LOG(f[d2]) + PT_LOG(f2[d0])) * 2);
+		else if (r < pc->g[1] + pc->g[2]) ex[r] = (float)(PT_LOG(2.0) + PT_LOG(f[d2]) * 2 + PT_LOG(f2[d0]) + PT_LOG(f2[d1]));
+		else if (r < pc->g[1] + pc->g[2] + pc->g[3]) ex[r] = (float)(PT_LOG(2.0) + PT_LOG(f2[d1]) * 2 + PT_LOG(f[d3]) + PT_LOG(f[d2]));
+		else {
+			ex[r] = (float)PT_LOG(4.0);
+			ex[r] += (float)PT_LOG(f2[d0]);
+			ex[r] += (float)PT_LOG(f2[d1]);
+			ex[r] += (float)PT_LOG(f[d2]);
+			ex[r] += (float)PT_LOG(f[d3]);
+		}
+	}
+}
+
+/* allo_genfreq (poly_geno.c:2122-2304) for one (cluster, locus): log genotype frequencies at selfing rate `self`, class by
+ * class from ijkl down to iikk (each class only needs the ones solved before it); *err |= 4 when one comes out positive */
+ISG_HD void PT_NAME(genfreq_row_allo)(float self, const isg_polyclass *pc, const float *ex, float *fr, int *err)
+{
+	const int n = pc->n, b1 = pc->g[1], b2 = b1 + pc->g[2], b3 = b2 + pc->g[3];
+	int r, v, w;
+	float temp;
+	for (r = b3; r < pc->G; r++) { /* ijkl */
+		fr[r] = (float)(PT_LOG((double)(1 - self)) + ex[r] - PT_LOG((double)(1 - self / 4)));
+		if (fr[r] > 0) *err |= 4;
+	}
+	for (r = b2; r < b3; r++) { /* ijkk: the second subgenome's homozygote comes from selfed heterozygotes k v */
+		const int code = pc->list[r], k = code % n, b = (code / n / n) % n, a = code / n / n / n;
+		temp = 0;
+		for (v = 0; v < n; v++)
+			if (v != k) temp = (float)(temp + PT_EXP((double)fr[isg_allo_row_any(n, a, b, k, v)]) * self / 8.0);
+		fr[r] = (float)(PT_LOG((1 - self) * PT_EXP((double)ex[r]) + temp) - PT_LOG(1 - self / 2.0));
+		if (fr[r] > 0) *err |= 4;
+	}
+	for (r = b1; r < b2; r++) { /* iikl */
+		const int code = pc->list[r], d = code % n, c = (code / n) % n, a = (code / n / n) % n;
+		temp = 0;
+		for (v = 0; v < n; v++)
+			if (v != a) temp = (float)(temp + PT_EXP((double)fr[isg_allo_row_any(n, a, v, c, d)]) * self / 8.0);
+		fr[r] = (float)(PT_LOG((1 - self) * PT_EXP((double)ex[r]) + temp) - PT_LOG(1 - self / 2.0));
+		if (fr[r] > 0) *err |= 4;
+	}
+	for (r = 0; r < b1; r++) { /* iikk */
+		const int code = pc->list[r], k = code % n, a = (code / n / n) % n;
+		temp = 0;
+		for (v = 0; v < n; v++)
+			if (v != k) temp = (float)(temp + PT_EXP((double)fr[isg_allo_row_any(n, a, a, k, v)]) * self / 4.0);
+		for (v = 0; v < n; v++)
+			if (v != a) temp = (float)(temp + PT_EXP((double)fr[isg_allo_row_any(n, a, v, k, k)]) * self / 4.0);
+		for (v = 0; v < n; v++)
+			for (w = 0; w < n; w++)
+				if (v != a && w != k) temp = (float)(temp + PT_EXP((double)fr[isg_allo_row_any(n, a, v, k, w)]) * self / 16.0);
+		fr[r] = (float)(PT_LOG((1 - self) * PT_EXP((double)ex[r]) + temp) - PT_LOG((double)(1 - self)));
+		if (fr[r] > 0) *err |= 4;
 	}
 }

@@ -8,7 +8,11 @@
  * NOT part of the product.  The MI355X kernels for this path are not written yet;
  * this file and its fixtures are the parity anchor they will be built against.
  *
- * usage (dump tool, main() below): orc_dump_poly data.txt out K N L u b t e r j s1 s2 s3
+ * Allotetraploid (-ap 0; fourth switch): update_P_allo (poly_geno.c:441-518), calc_exfreq_allo (:1592-1670), allo_genfreq
+ * (:2122-2304), choose_two/tri/tetra_allo (:962-1215) and the two-subgenome terms of calc_genofq (:1262-1282); pinned to
+ * tests/golden/ta*.golden the same way.
+ *
+ * usage (dump tool, main() below): orc_dump_poly data.txt out K N L u b t e r j s1 s2 s3 [math accum [keyed [allo]]]
  */
 #include <math.h>
 #include <stdint.h>
@@ -136,7 +140,8 @@ static int disc_unif(double *vec, int length) /* random.c:403-430 */
 static int N, L, K, Amax, back_refl;
 static int *allelenum, *obs, *alleleid;    /* obs [N][L][4] sorted distinct codes, alleleid [N][L] */
 static int *z, *geno, *state;              /* [N][L][4] */
-static double *freq, *qq, *qqnum, *S, *indvlkh, alpha, totallkh;
+static double *freq, *freq2, *qq, *qqnum, *S, *indvlkh, alpha, totallkh;
+static int g_allo;                         /* 1: allotetraploid (-ap 0): copies 0, 1 / 2, 3 belong to two subgenomes (freq / freq2) */
 /* POLY (poly_geno.h:10-21) */
 static int num_allele, *allele_poly, (*genonum)[6], **genolist;
 static float **exfreq, **genofreq;         /* [K*L] -> float[G] */
@@ -146,6 +151,7 @@ static int err_flag;
 #define Z(i, j, k) z[((long)(i) * L + (j)) * P4 + (k)]
 #define GENO(i, j, k) geno[((long)(i) * L + (j)) * P4 + (k)]
 #define FREQ(k, j, a) freq[((long)(k) * L + (j)) * Amax + (a)]
+#define FREQ2(k, j, a) freq2[((long)(k) * L + (j)) * Amax + (a)]
 #define VALID(i, j) (alleleid[(long)(i) * L + (j)] != 0)
 
 static int exists(int value, const int *vec, int leng) /* data_interface.c:865-877 */
@@ -178,8 +184,9 @@ static void gen_polyinfo(void) /* poly_geno.c:143-184, 1673-1800 */
 	genolist = malloc(sizeof(int *) * cnt);
 	pclass = malloc(sizeof(isg_polyclass) * cnt);
 	for (i = 0; i < cnt; i++) {
-		genolist[i] = malloc(sizeof(int) * (isg_poly_G(allele_poly[i]) + 1));
-		isg_poly_build(allele_poly[i], genonum[i], genolist[i]);
+		genolist[i] = malloc(sizeof(int) * ((g_allo ? isg_allo_G(allele_poly[i]) : isg_poly_G(allele_poly[i])) + 1));
+		if (g_allo) isg_allo_build(allele_poly[i], genonum[i], genolist[i]);
+		else isg_poly_build(allele_poly[i], genonum[i], genolist[i]);
 		pclass[i].n = allele_poly[i];
 		pclass[i].G = genonum[i][0];
 		memcpy(pclass[i].g, genonum[i], sizeof(int) * 6);
@@ -209,9 +216,22 @@ static void tri_allele_auto(int num, int i, int j) /* poly_geno.c:2509-2530 */
 	else if (num == 2) set_geno(i, j, b, b, a, c);
 	else if (num == 3) set_geno(i, j, c, c, a, b);
 }
+/* two / tri / tetra_allele_allo (poly_geno.c:2466-2507, 2532-2612, 2614-2656): candidate `num` (1-based) as positions into
+ * the observed allele list, first subgenome's pair then the second's */
+static const signed char ALLO2[7][4] = {{0, 0, 0, 1}, {0, 1, 0, 0}, {0, 0, 1, 1}, {1, 1, 0, 0}, {0, 1, 1, 1}, {1, 1, 0, 1}, {0, 1, 0, 1}};
+static const signed char ALLO3[12][4] = {{0, 0, 1, 2}, {1, 2, 0, 0}, {1, 1, 0, 2}, {0, 2, 1, 1}, {2, 2, 0, 1}, {0, 1, 2, 2},
+					 {0, 1, 1, 2}, {1, 2, 0, 1}, {1, 2, 0, 2}, {0, 2, 1, 2}, {0, 2, 0, 1}, {0, 1, 0, 2}};
+static const signed char ALLO4[6][4] = {{0, 1, 2, 3}, {2, 3, 0, 1}, {0, 2, 1, 3}, {1, 3, 0, 2}, {0, 3, 1, 2}, {1, 2, 0, 3}};
+static const signed char *allo_pattern(int naid, int num) { return naid == 2 ? ALLO2[num - 1] : naid == 3 ? ALLO3[num - 1] : ALLO4[num - 1]; }
+static int allo_ncand(int naid) { return naid == 2 ? 7 : naid == 3 ? 12 : 6; } /* POLY.num_allogeno, poly_geno.c:146-149 */
+static void set_allo(int num, int naid, int i, int j)
+{
+	const signed char *p = allo_pattern(naid, num);
+	set_geno(i, j, OBS(i, j, p[0]), OBS(i, j, p[1]), OBS(i, j, p[2]), OBS(i, j, p[3]));
+}
 static int choose_unif(int temp) /* poly_geno.c:840-852 */
 {
-	double tmp[8];
+	double tmp[16];
 	int j;
 	for (j = 0; j < temp; j++) tmp[j] = (double)(j + 1) / (double)temp;
 	return disc_unif(tmp, temp) + 1;
@@ -223,6 +243,7 @@ static void initial_geno(void) /* poly_geno.c:316-369 (autopoly) */
 	for (i = 0; i < N; i++)
 		for (j = 0; j < L; j++) {
 			if (!VALID(i, j)) continue;
+			if (g_allo && alleleid[(long)i * L + j] > 1) { set_allo(choose_unif(allo_ncand(alleleid[(long)i * L + j])), alleleid[(long)i * L + j], i, j); continue; }
 			switch (alleleid[(long)i * L + j]) {
 			case 1: for (k = 0; k < P4; k++) GENO(i, j, k) = OBS(i, j, 0); break;
 			case 2: two_allele_auto(choose_unif(3), i, j); break;
@@ -251,11 +272,36 @@ static void update_P_auto(void) /* poly_geno.c:390-438 */
 	free(tmp);
 }
 
-static void calc_exfreq_auto(void) /* poly_geno.c:1515-1590 */
+static void update_P_allo(void) /* poly_geno.c:441-518: per (cluster, locus) the first subgenome's Dirichlet, then the second's */
+{
+	int *cnt = calloc((size_t)2 * K * L * Amax, sizeof(int)), *cnt2 = cnt + (size_t)K * L * Amax;
+	double *tmp = malloc(sizeof(double) * Amax);
+	int i, j, k;
+	for (i = 0; i < N; i++)
+		for (j = 0; j < L; j++)
+			if (VALID(i, j))
+				for (k = 0; k < P4; k++) (k < P4 / 2 ? cnt : cnt2)[((long)Z(i, j, k) * L + j) * Amax + GENO(i, j, k)]++;
+	for (i = 0; i < K; i++)
+		for (j = 0; j < L; j++) {
+			for (k = 0; k < allelenum[j]; k++) tmp[k] = (double)cnt[((long)i * L + j) * Amax + k];
+			rdirich(tmp, allelenum[j], &FREQ(i, j, 0), 1.0);
+			for (k = 0; k < allelenum[j]; k++) tmp[k] = (double)cnt2[((long)i * L + j) * Amax + k];
+			rdirich(tmp, allelenum[j], &FREQ2(i, j, 0), 1.0);
+		}
+	free(cnt);
+	free(tmp);
+}
+
+static void calc_exfreq_auto(void) /* poly_geno.c:1515-1590; -ap 0: calc_exfreq_allo :1592-1670 */
 {
 	int i, k;
 	for (k = 0; k < K; k++)
 		for (i = 0; i < L; i++) {
+			if (g_allo) {
+				if (g_math) pti_exfreq_row_allo(&pclass[nid_of(i)], &FREQ(k, i, 0), &FREQ2(k, i, 0), exfreq[k * L + i]);
+				else ptl_exfreq_row_allo(&pclass[nid_of(i)], &FREQ(k, i, 0), &FREQ2(k, i, 0), exfreq[k * L + i]);
+				continue;
+			}
 			if (g_math) pti_exfreq_row(&pclass[nid_of(i)], &FREQ(k, i, 0), exfreq[k * L + i]);
 			else ptl_exfreq_row(&pclass[nid_of(i)], &FREQ(k, i, 0), exfreq[k * L + i]);
 		}
@@ -265,6 +311,11 @@ static void calc_self_genofreq(double self_rate, float **tab, int k, int own) /*
 	int i, e = 0;
 	for (i = 0; i < L; i++) {
 		float *out = own ? tab[k * L + i] : tab[i];
+		if (g_allo) {
+			if (g_math) pti_genfreq_row_allo((float)self_rate, &pclass[nid_of(i)], exfreq[k * L + i], out, &e);
+			else ptl_genfreq_row_allo((float)self_rate, &pclass[nid_of(i)], exfreq[k * L + i], out, &e);
+			continue;
+		}
 		if (g_math) pti_genfreq_row((float)self_rate, &pclass[nid_of(i)], exfreq[k * L + i], out, &e);
 		else ptl_genfreq_row((float)self_rate, &pclass[nid_of(i)], exfreq[k * L + i], out, &e);
 	}
@@ -287,7 +338,7 @@ static int get_cat_auto(const int *g) /* poly_geno.c:1313-1339 */
 static int get_index_auto(int j, const int *g, int *cat) /* poly_geno.c:1289-1311 */
 {
 	int i, temp = g[0], id = nid_of(j);
-	*cat = get_cat_auto(g);
+	*cat = g_allo ? isg_allo_cat(g) : get_cat_auto(g); /* get_cat_allo, poly_geno.c:1341-1372 */
 	for (i = 1; i < P4; i++) temp = temp * allelenum[j] + g[i];
 	return find_id(temp, genolist[id], genonum[id][0]);
 }
@@ -301,6 +352,16 @@ static double calc_genofq(int j, int i, const int *zz) /* poly_geno.c:1235-1286 
 	if (g_accum) { /* canonical: the terms are accumulated exactly by the caller */
 		err_flag |= 8;
 		return 0;
+	}
+	if (g_allo) { /* poly_geno.c:1262-1282 */
+		for (m = 0; m < P4 / 2; m++) ld += m_log(FREQ(zz[m], j, GENO(i, j, m)));
+		for (m = P4 / 2; m < P4; m++) ld += m_log(FREQ2(zz[m], j, GENO(i, j, m)));
+		switch (cat) {
+		case 1: ld += m_log(2); break;
+		case 2: ld += m_log(2); break;
+		case 3: ld += m_log(4); break;
+		}
+		return ld;
 	}
 	for (m = 0; m < P4; m++) ld += m_log(FREQ(zz[m], j, GENO(i, j, m)));
 	switch (cat) {
@@ -320,6 +381,13 @@ static void add_terms(summer *t, int i, int j, int id, float **tab)
 	if (chcksame(zz, P4) == 0) {
 		if (tab && id == zz[0]) sum_add(t, (double)tab[j][gid]);
 		else sum_add(t, (double)genofreq[zz[0] * L + j][gid]);
+		return;
+	}
+	if (g_allo) {
+		for (m = 0; m < P4 / 2; m++) sum_add(t, m_log(FREQ(zz[m], j, GENO(i, j, m))));
+		for (m = P4 / 2; m < P4; m++) sum_add(t, m_log(FREQ2(zz[m], j, GENO(i, j, m))));
+		if (cat == 1 || cat == 2) sum_add(t, m_log(2));
+		if (cat == 3) sum_add(t, m_log(4));
 		return;
 	}
 	for (m = 0; m < P4; m++) sum_add(t, m_log(FREQ(zz[m], j, GENO(i, j, m))));
@@ -377,6 +445,14 @@ static double cal_lkd_props(int id, float **tab) /* poly_geno.c:645-711 */
 			if (chcksame(&Z(i, j, 0), P4) == 0) {
 				if (id == Z(i, j, 0)) ld += (double)tab[j][gid];
 				else ld += (double)genofreq[Z(i, j, 0) * L + j][gid];
+			} else if (g_allo) { /* poly_geno.c:691-706 */
+				for (m = 0; m < P4 / 2; m++) ld += log(FREQ(Z(i, j, m), j, GENO(i, j, m)));
+				for (m = P4 / 2; m < P4; m++) ld += log(FREQ2(Z(i, j, m), j, GENO(i, j, m)));
+				switch (cat) {
+				case 1: ld += log(2); break;
+				case 2: ld += log(2); break;
+				case 3: ld += log(4); break;
+				}
 			} else {
 				for (m = 0; m < P4; m++) ld += log(FREQ(Z(i, j, m), j, GENO(i, j, m)));
 				switch (cat) {
@@ -516,6 +592,48 @@ static int choose_auto(int i, int j, int n_type) /* choose_two_auto / choose_tri
 	for (a = 1; a < 3; a++) tmp[a] += tmp[a - 1];
 	return disc_unif(tmp, 3) + 1;
 }
+/* choose_two / tri / tetra_allo (poly_geno.c:962-1215): the candidates' weights are the cluster's genotype frequencies when
+ * all four copies sit in one cluster, else products of the individual's expected allele frequencies in the two subgenomes
+ * (a factor 2 when both pairs are heterozygous: candidates 7 of two alleles and 7..12 of three) */
+static int choose_allo(int i, int j, int naid)
+{
+	const int nc = allo_ncand(naid), n = allelenum[j];
+	double tmp[12], fq[4], fq2[4], tm;
+	int a, b;
+	if (chcksame(&Z(i, j, 0), P4) == 0) {
+		for (a = 0; a < nc; a++) {
+			const signed char *p = allo_pattern(naid, a + 1);
+			tmp[a] = (double)genofreq[Z(i, j, 0) * L + j][isg_allo_row(n, OBS(i, j, p[0]), OBS(i, j, p[1]), OBS(i, j, p[2]), OBS(i, j, p[3]))];
+		}
+	} else {
+		for (a = 0; a < naid; a++) {
+			fq[a] = 0;
+			fq2[a] = 0;
+			for (b = 0; b < K; b++) {
+				fq[a] += qq[(long)i * K + b] * FREQ(b, j, OBS(i, j, a));
+				fq2[a] += qq[(long)i * K + b] * FREQ2(b, j, OBS(i, j, a));
+			}
+		}
+		for (a = 0; a < nc; a++) {
+			const signed char *p = allo_pattern(naid, a + 1);
+			const int hetA = p[0] != p[1], hetB = p[2] != p[3];
+			/* the reference writes each sum out term by term; the order of its terms: [log 2 +] first pair, second pair, with a
+			 * homozygous pair as 2 log f */
+			double v = 0;
+			int first = 1;
+			if (hetA && hetB && naid < 4) { v = m_log(2); first = 0; }
+			if (hetA) { v = first ? m_log(fq[p[0]]) : v + m_log(fq[p[0]]); first = 0; v += m_log(fq[p[1]]); }
+			else { v = first ? 2 * m_log(fq[p[0]]) : v + 2 * m_log(fq[p[0]]); first = 0; }
+			if (hetB) { v += m_log(fq2[p[2]]); v += m_log(fq2[p[3]]); }
+			else v += 2 * m_log(fq2[p[2]]);
+			tmp[a] = v;
+		}
+	}
+	tm = tmp[0];
+	for (a = 0; a < nc; a++) tmp[a] = m_exp(tmp[a] - tm);
+	for (a = 1; a < nc; a++) tmp[a] += tmp[a - 1];
+	return disc_unif(tmp, nc) + 1;
+}
 static void update_geno(void) /* poly_geno.c:520-580 (autopoly); the canonical-order fix-up never fires for -ap 1 */
 {
 	int i, j, k;
@@ -523,6 +641,7 @@ static void update_geno(void) /* poly_geno.c:520-580 (autopoly); the canonical-o
 	for (i = 0; i < N; i++)
 		for (j = 0; j < L; j++) {
 			if (!VALID(i, j)) continue;
+			if (g_allo && alleleid[(long)i * L + j] > 1) { set_allo(choose_allo(i, j, alleleid[(long)i * L + j]), alleleid[(long)i * L + j], i, j); continue; }
 			switch (alleleid[(long)i * L + j]) {
 			case 1: for (k = 0; k < P4; k++) GENO(i, j, k) = OBS(i, j, 0); break;
 			case 2: two_allele_auto(choose_auto(i, j, 2), i, j); break;
@@ -618,9 +737,11 @@ int main(int argc, char **argv)
 	double c_tot = 1, c_tot2 = 1, *c_indv, *c_S, *c_qq;
 	long c_step = 0, steps;
 	int flag_empty = 0;
-	if (argc != 15 && argc != 17 && argc != 18) { fprintf(stderr, "usage: orc_dump_poly data out K N L u b t e r j s1 s2 s3 [math accum [keyed]]\n"); return 2; }
+	if (argc != 15 && argc != 17 && argc != 18 && argc != 19) { fprintf(stderr, "usage: orc_dump_poly data out K N L u b t e r j s1 s2 s3 [math accum [keyed [allo]]]\n"); return 2; }
 	if (argc >= 17) { g_math = atoi(argv[15]); g_accum = atoi(argv[16]); }
-	if (argc == 18) g_keyed = atoi(argv[17]);
+	if (argc >= 18) g_keyed = atoi(argv[17]);
+	if (argc == 19) g_allo = atoi(argv[18]);
+	if (g_allo && g_keyed) { fprintf(stderr, "the keyed schedule is not defined for -ap 0\n"); return 2; }
 	K = atoi(argv[3]); u = atol(argv[6]); b = atol(argv[7]); t = atoi(argv[8]); e = atoi(argv[9]); r = atoi(argv[10]); jj = atoi(argv[11]);
 	s1 = atoi(argv[12]); s2 = atoi(argv[13]); s3 = atoi(argv[14]);
 	back_refl = e;
@@ -629,13 +750,13 @@ int main(int argc, char **argv)
 	initd = malloc(sizeof(float) * K);
 	for (i = 0; i < K; i++) initd[i] = (float)ran1();
 	z = calloc((size_t)N * L * P4, sizeof(int)); geno = calloc((size_t)N * L * P4, sizeof(int)); state = calloc(K, sizeof(int));
-	freq = calloc((size_t)K * L * Amax, sizeof(double)); qq = calloc((size_t)N * K, sizeof(double)); qqnum = calloc((size_t)N * K, sizeof(double));
+	freq = calloc((size_t)K * L * Amax, sizeof(double)); freq2 = calloc((size_t)K * L * Amax, sizeof(double)); qq = calloc((size_t)N * K, sizeof(double)); qqnum = calloc((size_t)N * K, sizeof(double));
 	S = calloc(K, sizeof(double)); indvlkh = calloc(N, sizeof(double));
 	vflat = malloc(sizeof(int) * N * L); gflat = malloc(sizeof(int) * N * L * P4); cflat = malloc(sizeof(int) * K * L * Amax);
 	for (i = 0; i < N; i++) for (j = 0; j < L; j++) vflat[i * L + j] = VALID(i, j);
 	D.N = N; D.L = L; D.P = P4; D.K = K; D.Amax = Amax; D.allelenum = allelenum; D.valid = vflat;
 	fprintf(G, "# instruct golden v1 ploidy 4 (generated by oracle/ref_dump_poly.c from the reference sweeps)\n");
-	fprintf(G, "cfg N=%d L=%d K=%d P=4 Amax=%d e=%d u=%ld b=%ld t=%d r=%d j=%d s=%d,%d,%d\n", N, L, K, Amax, e, u, b, t, r, jj, s1, s2, s3);
+	fprintf(G, "cfg N=%d L=%d K=%d P=4 Amax=%d e=%d u=%ld b=%ld t=%d r=%d j=%d s=%d,%d,%d%s\n", N, L, K, Amax, e, u, b, t, r, jj, s1, s2, s3, g_allo ? " ap=0" : "");
 	{
 		uint64_t h = fnv_init();
 		for (i = 0; i < N; i++) for (j = 0; j < L; j++) for (k = 0; k < P4; k++) h = fnv_i32(h, k < alleleid[i * L + j] ? OBS(i, j, k) : -1);
@@ -671,10 +792,13 @@ int main(int argc, char **argv)
 	fprintf(G, "chain zqinit hz=%016llx hqq=%016llx", (unsigned long long)hash_z(&D, z), (unsigned long long)hash_f64v(qq, (long)N * K)); SEEDS();
 	for (step = 0; step < u; step++) {
 		ky_iter = (uint64_t)step;
-		update_P_auto();
+		if (g_allo) update_P_allo();
+		else update_P_auto();
 		GFLAT();
 		count_alleles_plain(&D, gflat, z, cflat);
-		fprintf(G, "it %ld P hcnt=%016llx hfreq=%016llx", step, (unsigned long long)hash_counts(&D, cflat), (unsigned long long)hash_freq(&D, freq)); SEEDS();
+		fprintf(G, "it %ld P hcnt=%016llx hfreq=%016llx", step, (unsigned long long)hash_counts(&D, cflat), (unsigned long long)hash_freq(&D, freq));
+		if (g_allo) fprintf(G, " hfreq2=%016llx", (unsigned long long)hash_freq(&D, freq2));
+		SEEDS();
 		calc_exfreq_auto();
 		fprintf(G, "it %ld X hexfreq=%016llx\n", step, (unsigned long long)hash_tables(exfreq));
 		update_S_POP();

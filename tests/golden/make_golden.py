@@ -55,6 +55,19 @@ POLY_CASES = {
 }
 
 
+# allotetraploid (-ap 0; update_P_allo, calc_exfreq_allo, allo_genfreq, choose_*_allo): same tuple layout
+ALLO_CASES = {
+    "ta1":    (50, 36, 3, 4, 0.05, 60, 30, 5, 1, 4, 4, (13, 4, 1972)),
+    "ta2_e0": (30, 30, 2, 3, 0.03, 60, 30, 5, 0, 4, 4, (14, 5, 1973)),
+    "ta3_a2": (40, 50, 3, 2, 0.00, 60, 30, 5, 1, 4, 4, (15, 6, 1974)),
+}
+
+
+def allo_data_for(name):
+    N, L, K, A, miss = ALLO_CASES[name][:5]
+    return synth.raw_alleles(N, L, K, 4, A, miss, 20260301 + sorted(ALLO_CASES).index(name))
+
+
 def poly_data_for(name):
     N, L, K, A, miss = POLY_CASES[name][:5]
     return synth.raw_alleles(N, L, K, 4, A, miss, 20260201 + sorted(POLY_CASES).index(name))
@@ -89,6 +102,20 @@ def main():
         with open(os.devnull, "w") as devnull:
             subprocess.check_call(args, stdout=devnull)
         print(name, os.path.getsize(out), "bytes")
+    for name, cfg in ALLO_CASES.items():
+        N, L, K, A, miss, u, b, t, e, r, j, seeds = cfg
+        txt = os.path.join(HERE, name + ".txt")
+        synth.write_text_polyploid(txt, allo_data_for(name))
+        out = os.path.join(HERE, name + ".golden")
+        args = [os.path.join(REF, "ref_dump_poly"), txt, out] + [str(x) for x in (K, N, L, u, b, t, e, r, j) + tuple(seeds)] + ["0"]
+        with open(os.devnull, "w") as devnull:
+            subprocess.check_call(args, stdout=devnull)
+        print(name, os.path.getsize(out), "bytes")
+    cmd = [CLI_REF, "-d", "ta1.txt", "-o", "ta1_cli_output.txt"] + ALLO_CLI
+    if os.path.exists(os.path.join(HERE, "ta1_cli_output.txt")):
+        os.unlink(os.path.join(HERE, "ta1_cli_output.txt"))
+    with open(os.devnull, "w") as devnull:
+        subprocess.check_call(cmd, stdout=devnull, cwd=HERE)
     # end-to-end reference CLI output for the drop-in test (result file at %.3f)
     # (this one was committed with absolute paths on its command-line echo; kept so that regenerating reproduces the bytes)
     cmd = [os.path.join(REF, "InStruct_ref"), "-d", os.path.join(HERE, "c1.txt"), "-o", os.path.join(HERE, "c1_cli_output.txt"), "-K", "3", "-L", "100", "-N", "50", "-p", "2",
@@ -179,6 +206,9 @@ MODE5_CLI = ["-K", "3", "-L", "100", "-N", "50", "-p", "2", "-u", "200", "-b", "
 
 MODE0_CLI = ["-K", "3", "-L", "100", "-N", "50", "-p", "2", "-u", "200", "-b", "100", "-t", "10", "-c", "2", "-v", "0", "-g", "1", "-r", "5",
              "-j", "5", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "1"]
+
+ALLO_CLI = ["-K", "3", "-L", "36", "-N", "50", "-p", "4", "-ap", "0", "-af", "1", "-u", "60", "-b", "30", "-t", "5", "-c", "2",
+            "-v", "2", "-g", "1", "-r", "4", "-j", "4", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "0"]
 
 TETRA_CLI = ["-K", "3", "-L", "40", "-N", "60", "-p", "4", "-ap", "1", "-af", "1", "-u", "60", "-b", "30", "-t", "5", "-c", "2",
              "-v", "2", "-g", "1", "-r", "4", "-j", "4", "-lb", "0", "-a", "0", "-s", "13", "4", "1972", "-pi", "0", "-pf", "0"]
