@@ -71,13 +71,24 @@ def timed_steps(chain, steps, warmup, world):
     return dt, lk, prof
 
 
+# the replay schedule's update_ZQ is a PHASE of kernels: the uniforms as floats, one k_zq_block launch per block of individuals
+# (start positions), then the sweep at the resolved positions.  Its roofline entry is the phase: 2 N L P bytes / phase time.
+ZQ_RESOLVE = ("k_tapef", "k_zq_block", "k_zq_at")
+
+
 def roofline(prof, kernel, bytes_per_launch, traffic):
-    ms, n = prof[kernel]
+    if isinstance(kernel, tuple):
+        ms = sum(prof[k][0] for k in kernel)
+        n = prof[kernel[-1]][1]
+        name = "update_ZQ phase: " + " + ".join(kernel)
+    else:
+        ms, n = prof[kernel]
+        name = kernel
     avg_s = ms / n * 1e-3
     gbs = bytes_per_launch / avg_s / 1e9
-    return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 6), "avg_launch_ms": round(ms / n, 4), "alg_bytes_per_launch": bytes_per_launch,
-            "traffic": traffic}
+            "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)"}
 
 
 def load_traffic():
@@ -282,9 +293,17 @@ def main():
         ch.setseeds(*seeds)
         ch.chain_init(np.array([ch.ran1() for _ in range(K)], dtype=np.float32))
         dt, lk, prof = timed_steps(ch, args.steps, args.warmup, world)
-        zq = next(k for k in ("k_zq_pipe", "k_zq_spec", "k_zq_coop", "k_zq_chain") if k in prof) if sched == capi.SCHED_REPLAY else "k_zq_keyed"
-        # update_ZQ launch: reads the genotype byte and writes the Z byte of every allele copy
-        rl = roofline(prof, zq, 2 * N * L * P, traffic.get(zq))
+        if sched != capi.SCHED_REPLAY:
+            zq = "k_zq_keyed"
+        elif "k_zq_block" in prof:
+            zq = ZQ_RESOLVE
+        else:
+            zq = next(k for k in ("k_zq_pipe", "k_zq_spec", "k_zq_coop", "k_zq_chain") if k in prof)
+        # update_ZQ: reads the genotype byte and writes the Z byte of every allele copy
+        rl = roofline(prof, zq, 2 * N * L * P, traffic.get("update_ZQ_replay" if isinstance(zq, tuple) else zq))
+        if isinstance(zq, tuple):
+            rl["resolve"] = ch.zq_resolve_stats()
+            rl["fallback_sweeps"] = ch.zq_fallbacks()
         ckrep = min(len(lk), 20)
         gr = None
         if world > 1:

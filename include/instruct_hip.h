@@ -49,7 +49,7 @@ typedef struct {
 	int32_t back_refl; /* -e (InStruct.c:45) */
 	int32_t rng_sched; /* ISG_SCHED_* */
 	int32_t device;    /* HIP device ordinal */
-	int32_t reserved[7];
+	int32_t reserved[7]; /* reserved[0] (ploidy 4 only): 1 = allotetraploid, -ap 0 (SEQDATA.autopoly == 0); 0 = autotetraploid */
 } isg_config;
 
 /* problem upload + device state allocation (replaces allocate_node, mcmc.c:506-546) */
@@ -138,12 +138,20 @@ int isg_keyed_layout(isg_ctx *ctx, uint64_t out[9]);
  *   isg_cal_lkh         cal_lkd                                           poly_geno.c:715-735
  *   isg_iteration       P, S_POP, ZQ, geno, lkd in the reference's order  poly_geno.c:98-116
  * isg_update_G / isg_update_alpha fail: the reference has no such sweep on this path.
+ *
+ * Allotetraploid (`-p 4 -ap 0`, cfg.reserved[0] = 1; replay schedule): a genotype is a pair of diploid genotypes, copies
+ * 0, 1 from the first subgenome (allele frequencies freq), copies 2, 3 from the second (freq2).  Same entry points:
+ *   isg_update_P = update_P_allo + calc_exfreq_allo (poly_geno.c:441-518, 1592-1670; per (cluster, locus) the first
+ *   subgenome's Dirichlet, then the second's); update_S_POP with allo_genfreq (:2122-2304); update_ZQ unchanged (it uses
+ *   freq for all four copies, poly_geno.c:772); isg_poly_update_geno = choose_two / tri / tetra_allo (:962-1215: 7, 12, 6
+ *   candidates, one uniform per locus with two or more observed alleles); cal_lkd with the two-subgenome terms (:1262-1282).
  */
 int isg_ctx_create_poly(const isg_config *cfg, const int32_t *allelenum, const int32_t *seqdata, const int32_t *alleleid, isg_ctx **out);
 int isg_poly_update_geno(isg_ctx *ctx);
 int isg_get_poly_geno(isg_ctx *ctx, int32_t *geno);               /* [N][L][4] imputed genotypes (UPMCMC.geno), -1 unused */
 int isg_get_poly_gs(isg_ctx *ctx, int32_t *gs, int32_t *gcount);  /* table row stride; genotypes per locus [L] (may be NULL) */
 int isg_get_poly_table(isg_ctx *ctx, int which, float *out);      /* 0 exfreq, 1 genofreq: float [K][L][gs] */
+int isg_get_poly_freq2(isg_ctx *ctx, double *freq2);              /* [K][L][Amax], allotetraploid contexts */
 
 /* CHAIN running means on the device: allocate_chn + initialize_chn (mcmc.c:588-738) and store_chn (mcmc.c:1320-1456)
  * for everything that is O(N K) or O(K L A) -- qq, qq2, indvlkh, gen, gen2 and, with_freq (-pf 1, ploidy 2), freq,

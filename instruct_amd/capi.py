@@ -25,7 +25,7 @@ EXPORTS = [
     "isg_set_generation", "isg_set_self_rates", "isg_set_alpha", "isg_keyed_layout", "isg_profile_enable",
     "isg_profile_count", "isg_profile_get", "isg_profile_reset", "isg_gelman_rubin", "isg_selftest",
     "isg_store_begin", "isg_store_step", "isg_store_fetch", "isg_zq_fallbacks", "isg_zq_resolve_stats", "isg_gather_convg",
-    "isg_ctx_create_poly", "isg_poly_update_geno", "isg_get_poly_geno", "isg_get_poly_gs", "isg_get_poly_table",
+    "isg_ctx_create_poly", "isg_poly_update_geno", "isg_get_poly_geno", "isg_get_poly_gs", "isg_get_poly_table", "isg_get_poly_freq2",
 ]
 
 
@@ -272,14 +272,17 @@ class HipPolyChain(HipChain):
     (0 = missing) -- SEQDATA.seqdata / SEQDATA.alleleid as transform_data2 (data_interface.c:571-669) leaves them.
     """
 
-    def __init__(self, obs, alleleid, allelenum, K, back_refl=1, rng_sched=SCHED_REPLAY, device=0):
+    def __init__(self, obs, alleleid, allelenum, K, back_refl=1, rng_sched=SCHED_REPLAY, device=0, allo=False):
+        """allo=True: allotetraploid (``-ap 0``): two subgenomes with their own allele frequencies (freq / freq2)"""
         self.lib = load()
+        self.allo = bool(allo)
         obs = np.ascontiguousarray(obs, dtype=np.int32)
         self.N, self.L, self.P = obs.shape
         self.K = K
         allelenum = np.ascontiguousarray(allelenum, dtype=np.int32)
         alleleid = np.ascontiguousarray(alleleid, dtype=np.int32)
         cfg = IsgConfig(self.N, self.L, self.P, K, 2, 1, back_refl, rng_sched, device)
+        cfg.reserved[0] = 1 if allo else 0
         h = C.c_void_p()
         self._chk(self.lib.isg_ctx_create_poly(C.byref(cfg), _ptr(allelenum), _ptr(obs), _ptr(alleleid), C.byref(h)))
         self.h = h
@@ -294,6 +297,10 @@ class HipPolyChain(HipChain):
 
     def update_geno(self):
         self._chk(self.lib.isg_poly_update_geno(self.h))
+
+    def freq2(self):
+        """second subgenome's allele frequencies [K][L][Amax] (UPMCMC.freq2, allotetraploid)"""
+        return self._get("isg_get_poly_freq2", (self.K, self.L, self.Amax), np.float64)
 
     def geno(self):
         return self._get("isg_get_poly_geno", (self.N, self.L, 4), np.int32)

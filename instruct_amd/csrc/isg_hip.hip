@@ -3824,7 +3824,13 @@ extern "C" int isg_get_poly_gs(isg_ctx *c, int32_t *gs, int32_t *gcount /* [L] g
 	if (!c->poly) return fail("isg_get_poly_gs: not a ploidy 4 context");
 	*gs = c->poly->p.GS;
 	if (gcount)
-		for (int j = 0; j < c->cfg.L; j++) gcount[j] = isg_poly_G(c->allelenum[j]);
+		for (int j = 0; j < c->cfg.L; j++) gcount[j] = c->poly->p.allo ? isg_allo_G(c->allelenum[j]) : isg_poly_G(c->allelenum[j]);
+	return 0;
+}
+extern "C" int isg_get_poly_freq2(isg_ctx *c, double *f) /* [K][L][Amax]: the second subgenome's allele frequencies (UPMCMC.freq2, -ap 0) */
+{
+	if (!c->poly || !c->poly->p.allo) return fail("isg_get_poly_freq2: not an allotetraploid context");
+	memcpy(f, c->poly->freq2_h.data(), sizeof(double) * c->poly->freq2_h.size());
 	return 0;
 }
 extern "C" int isg_get_poly_table(isg_ctx *c, int which, float *out)

@@ -26,7 +26,6 @@
 
 void printseeds(FILE *fp); /* random.c:60-63 */
 double ran1(void);         /* random.c:34-47 */
-CHAIN mcmc_POP_tetra_selfing(SEQDATA data, INIT initial, int chn, CONVG *cvg) __attribute__((weak)); /* poly_geno.h:23 */
 
 #define MIN2(X, Y) (((X) > (Y)) ? (Y) : (X))
 
@@ -430,6 +429,7 @@ static isg_ctx *get_ctx(SEQDATA d)
 				for (k = 0; k < 4; k++) geno[(i * L + j) * 4 + k] = k < d.alleleid[i][j] ? d.seqdata[i][j][k] : -1;
 			}
 		cfg.rng_sched = ISG_SCHED_REPLAY;
+		cfg.reserved[0] = (d.autopoly == 0); /* allotetraploid: two subgenomes (freq, freq2) */
 		if (isg_ctx_create_poly(&cfg, d.allelenum, geno, miss, &g_ctx)) hip_fail("isg_ctx_create_poly");
 	} else {
 		for (i = 0; i < N; i++)
@@ -657,8 +657,7 @@ CHAIN mcmc_updating(SEQDATA data, INIT initial, int chn, CONVG *cvg) /* mcmc.c:6
 	if (data.ploid == 2 && data.mode == 0) return mcmc_hip_chain0(data, initial, chn, cvg);
 	if (data.ploid == 2 && (data.mode == 1 || data.mode == 2 || data.mode == 4 || ((data.mode == 3 || data.mode == 5) && data.prior_flag == 0)))
 		return mcmc_hip_chain(data, initial, chn, cvg);
-	if (data.ploid == 4 && data.autopoly == 1) return mcmc_hip_chain(data, initial, chn, cvg);
-	if (data.ploid == 4 && mcmc_POP_tetra_selfing) return mcmc_POP_tetra_selfing(data, initial, chn, cvg); /* -ap 0: reference code */
-	nrerror("this build of the sampler accelerates diploid modes 0, 1, 2, 4 and, with the uniform prior, 3 and 5 (-v 0 .. -v 5, -f 0) and autotetraploids (-p 4 -ap 1); other modes need the reference mcmc.c");
+	if (data.ploid == 4) return mcmc_hip_chain(data, initial, chn, cvg); /* -ap 1 autotetraploid, -ap 0 allotetraploid */
+	nrerror("this build of the sampler accelerates diploid modes 0, 1, 2, 4 and, with the uniform prior, 3 and 5 (-v 0 .. -v 5, -f 0) and tetraploids (-p 4, -ap 0 / 1); other modes need the reference mcmc.c");
 	return chain;
 }

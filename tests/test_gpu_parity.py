@@ -542,6 +542,23 @@ def test_dropin_cli_output_equals_reference_cli_output_ploidy4(tmp_path):
     assert body(str(out)) == body(os.path.join(gu.GOLDEN, "t1_cli_output.txt"))
 
 
+def test_dropin_cli_output_equals_reference_cli_output_allotetraploid(tmp_path):
+    """`-p 4 -ap 0`: the drop-in runs the allotetraploid chain on the device (no reference code left in that path:
+    tests/golden/ta1_cli_output.txt was written by the pure reference binary)"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "InStruct_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
+    out = tmp_path / "out.txt"
+    cmd = [exe, "-d", os.path.join(gu.GOLDEN, "ta1.txt"), "-o", str(out)] + gu.make_golden.ALLO_CLI
+    log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-2000:]
+
+    def body(path):
+        return [l for l in open(path, "rb").read().split(b"\n")
+                if not (l.strip().startswith((b"Data File:", b"Output File:")) or b"InStruct" in l and b"-d" in l)]
+    assert body(str(out)) == body(os.path.join(gu.GOLDEN, "ta1_cli_output.txt"))
+
+
 @pytest.mark.parametrize("which", ["mode0", "mode3", "mode4", "mode5"])
 def test_dropin_cli_output_equals_reference_cli_output_other_modes(which, tmp_path):
     """`-v 3 -f 0` (one selfing rate per individual, uniform prior) and `-v 4 -e 0` (population inbreeding

@@ -15,6 +15,7 @@ import orc
 pytestmark = pytest.mark.gpu
 DUMP = os.path.join(orc.ORC_DIR, "orc_dump_poly")
 POLY = gu.make_golden.POLY_CASES
+ALLO = gu.make_golden.ALLO_CASES
 
 
 # generated at test time (oracle run on the GPU box's host): more alleles (up to the 6 the build supports, 126
@@ -35,13 +36,15 @@ def extra_data(name):
     return synth.raw_alleles(N, L, K, 4, A, miss, 20260301 + sorted(EXTRA).index(name))
 
 
-def hip_lines(name, cfg=None, raw=None, sched=0, fast_coder=False):
+def hip_lines(name, cfg=None, raw=None, sched=0, fast_coder=False, allo=False):
     """Drives the C ABI sweep by sweep and formats the state as oracle/isg_oracle_poly.c's dump does."""
     from instruct_amd import capi, synth
-    N, L, K, A, miss, u, b, t, e, r, j, seeds = cfg or POLY[name]
+    N, L, K, A, miss, u, b, t, e, r, j, seeds = cfg or (ALLO[name] if allo else POLY[name])
     coder = synth.code_tetraploid_fast if fast_coder else synth.code_tetraploid
-    obs, alleleid, allelenum = coder(raw if raw is not None else gu.make_golden.poly_data_for(name))
-    ch = capi.HipPolyChain(obs, alleleid, allelenum, K, back_refl=e, rng_sched=sched)
+    if raw is None:
+        raw = gu.make_golden.allo_data_for(name) if allo else gu.make_golden.poly_data_for(name)
+    obs, alleleid, allelenum = coder(raw)
+    ch = capi.HipPolyChain(obs, alleleid, allelenum, K, back_refl=e, rng_sched=sched, allo=allo)
     ch.setseeds(*seeds)
     initd = np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32)
     lines = []
@@ -51,7 +54,8 @@ def hip_lines(name, cfg=None, raw=None, sched=0, fast_coder=False):
     lines.append("chain zqinit hz=%s hqq=%s" % (orc.fnv_i32(ch.z()), orc.fnv_f64(ch.qq())) + sd())
     for step in range(u):
         ch.update_P()
-        lines.append("it %d P hcnt=%s hfreq=%s" % (step, _hcnt(ch, allelenum), _hfreq(ch, allelenum)) + sd())
+        lines.append("it %d P hcnt=%s hfreq=%s" % (step, _hcnt(ch, allelenum), _hfreq(ch, allelenum)) +
+                     (" hfreq2=%s" % _hfreq(ch, allelenum, ch.freq2()) if allo else "") + sd())
         lines.append("it %d X hexfreq=%s" % (step, orc.fnv_i32(ch.packed(ch.exfreq()).view(np.int32))))
         ch.update_S_POP()
         s = "it %d S" % step + "".join(" " + float(x).hex() for x in ch.self_rates())
@@ -75,8 +79,8 @@ def _hcnt(ch, allelenum):
     return orc.fnv_i32(np.ascontiguousarray(c[:, mask]))
 
 
-def _hfreq(ch, allelenum):
-    f = ch.freq()
+def _hfreq(ch, allelenum, f=None):
+    f = ch.freq() if f is None else f
     mask = (np.arange(ch.Amax)[None, :] < allelenum[:, None]) & (allelenum[:, None] > 1)
     return orc.fnv_f64(np.ascontiguousarray(f[:, mask]))
 
@@ -125,6 +129,71 @@ def test_tetraploid_aborted_cooperative_sweep_is_redone_bit_exact(monkeypatch):
     want = hip_lines("t1")
     monkeypatch.setenv("INSTRUCT_ZQ_TEST_ABORT", "2")
     assert hip_lines("t1") == want
+
+
+# ---------------------------------------------------------------------------------------------- allotetraploid, -ap 0
+ALLO_EXTRA = {
+    "xa_a4k5": (60, 120, 5, 4, 0.05, 3, 1, 1, 1, 1, 1, (31, 7, 1999)),
+    "xa_a6k2": (30, 24, 2, 6, 0.05, 3, 1, 1, 0, 1, 1, (32, 8, 2000)),    # 6 alleles: 441 genotypes per locus
+    "xa_a3k9": (20, 700, 9, 3, 0.10, 2, 1, 1, 1, 1, 1, (33, 9, 2001)),   # several workgroups per individual, K > 8
+}
+
+
+def _allo_oracle(txt, out, cfg, canonical):
+    N, L, K, A, miss, u, b, t, e, r, j, seeds = cfg
+    args = [DUMP, txt, out] + [str(x) for x in (K, N, L, u, b, t, e, r, j) + tuple(seeds)] + (["1", "1"] if canonical else ["0", "0"]) + ["0", "1"]
+    assert subprocess.call(args) == 0
+    return [l for l in gu.parse(out) if l.startswith("it ") or l.startswith("chain zqinit")]
+
+
+@pytest.mark.parametrize("name", sorted(ALLO))
+def test_allotetraploid_bit_identical_to_canonical_oracle(name, tmp_path):
+    """-p 4 -ap 0 on the device (update_P_allo, calc_exfreq_allo, allo_genfreq, choose_*_allo, two-subgenome likelihood):
+    every dump line of the three golden cases equal to the canonical oracle's"""
+    want = _allo_oracle(os.path.join(gu.GOLDEN, name + ".txt"), str(tmp_path / (name + ".can")), ALLO[name], True)
+    got = hip_lines(name, allo=True)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert _norm(g) == _norm(w)
+
+
+@pytest.mark.parametrize("name", sorted(ALLO_EXTRA))
+def test_allotetraploid_generated_cases_bit_identical_to_canonical_oracle(name, tmp_path):
+    from instruct_amd import synth
+    cfg = ALLO_EXTRA[name]
+    raw = synth.raw_alleles(cfg[0], cfg[1], cfg[2], 4, cfg[3], cfg[4], 20260401 + sorted(ALLO_EXTRA).index(name))
+    txt = str(tmp_path / (name + ".txt"))
+    synth.write_text_polyploid(txt, raw)
+    want = _allo_oracle(txt, str(tmp_path / (name + ".can")), cfg, True)
+    got = hip_lines(name, cfg, raw, allo=True)
+    assert len(got) == len(want) == 1 + 6 * cfg[5]
+    for g, w in zip(got, want):
+        assert _norm(g) == _norm(w)
+
+
+@pytest.mark.parametrize("name", sorted(ALLO))
+def test_allotetraploid_matches_reference_golden(name):
+    """against the trajectories the REAL reference produced (oracle/ref_dump_poly.c ... 0): discrete state and seeds
+    identical after every sweep, doubles within 1e-9"""
+    want = [l for l in gu.parse(os.path.join(gu.GOLDEN, name + ".golden")) if l.startswith("it ") or l.startswith("chain zqinit")]
+    got = hip_lines(name, allo=True)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        fg, fw = gu.fields(g), gu.fields(w)
+        for key in ("hz", "hgeno", "hcnt", "hqqnum", "seeds"):
+            assert fg.get(key) == fw.get(key), (key, g, w)
+        assert [t for t in g.split() if t.startswith("st")] == [t for t in w.split() if t.startswith("st")]
+        a, bb = gu.floats(g), gu.floats(w)
+        assert len(a) == len(bb)
+        for x, y in zip(a, bb):
+            assert x == y or (x != x and y != y) or abs(x - y) <= 1e-9 * max(abs(x), abs(y)), (g, w)
+
+
+def test_allotetraploid_keyed_schedule_is_refused():
+    from instruct_amd import capi, synth
+    obs, alleleid, allelenum = synth.code_tetraploid(gu.make_golden.allo_data_for("ta3_a2"))
+    with pytest.raises(capi.IsgError, match="keyed schedule is not defined for allotetraploids"):
+        capi.HipPolyChain(obs, alleleid, allelenum, 3, rng_sched=1, allo=True)
 
 
 def _noseeds(line):
