@@ -18,8 +18,8 @@ POLY = gu.make_golden.POLY_CASES
 ALLO = gu.make_golden.ALLO_CASES
 
 
-# generated at test time (oracle run on the GPU box's host): more alleles (up to the 6 the build supports, 126
-# genotypes per locus), more clusters, both proposal kinds
+# generated at test time (oracle run on the GPU box's host): more alleles (6: 126 genotypes per locus; 10: 715), more
+# clusters, both proposal kinds
 EXTRA = {
     "x_a4k5": (120, 200, 5, 4, 0.05, 3, 1, 1, 1, 1, 1, (21, 7, 1999)),
     "x_a6k2": (40, 30, 2, 6, 0.05, 4, 1, 1, 0, 1, 1, (22, 8, 2000)),
@@ -27,6 +27,7 @@ EXTRA = {
     "x_a3k20": (30, 700, 20, 3, 0.05, 2, 1, 1, 1, 1, 1, (24, 10, 2002)),  # several workgroups per individual, K > 16
     "x_a4k3": (25, 1500, 3, 4, 0.20, 2, 1, 1, 0, 1, 1, (25, 11, 2003)),
     "x_wide": (3, 66500, 3, 3, 0.05, 2, 1, 1, 1, 1, 1, (26, 12, 2004)),   # more loci than 128 workgroups x 512 lanes: several passes
+    "x_a10k3": (60, 12, 3, 10, 0.05, 2, 1, 1, 1, 1, 1, (27, 13, 2005)),   # microsatellite-like: 10 alleles, 715 genotypes per locus
 }
 
 
@@ -136,6 +137,7 @@ ALLO_EXTRA = {
     "xa_a4k5": (60, 120, 5, 4, 0.05, 3, 1, 1, 1, 1, 1, (31, 7, 1999)),
     "xa_a6k2": (30, 24, 2, 6, 0.05, 3, 1, 1, 0, 1, 1, (32, 8, 2000)),    # 6 alleles: 441 genotypes per locus
     "xa_a3k9": (20, 700, 9, 3, 0.10, 2, 1, 1, 1, 1, 1, (33, 9, 2001)),   # several workgroups per individual, K > 8
+    "xa_a9k3": (50, 10, 3, 9, 0.05, 2, 1, 1, 1, 1, 1, (34, 10, 2002)),   # 9 alleles: 2673 genotypes per locus
 }
 
 
