@@ -117,6 +117,21 @@ def test_tetraploid_bit_identical_to_canonical_oracle(name, tmp_path):
         assert _norm(g) == _norm(w)
 
 
+@pytest.mark.parametrize("name", ["t1", "x_a3k20", "x_a4k3", "xa_a3k9"])
+def test_tetraploid_block_resolved_update_zq_gives_the_same_lines(name, monkeypatch):
+    """INSTRUCT_ZQ_RESOLVE_P4=1: replay update_ZQ with the start positions resolved block-wise (k4_zq_block) and one
+    parallel sweep at them -- same lines as the cooperative chain kernel (which the other tests pin to the oracle)"""
+    allo = name.startswith("xa_")
+    cfg = None if name in POLY else (ALLO_EXTRA[name] if allo else EXTRA[name])
+    raw = None
+    if cfg is not None:
+        from instruct_amd import synth
+        raw = synth.raw_alleles(cfg[0], cfg[1], cfg[2], 4, cfg[3], cfg[4], 20260401 + sorted(ALLO_EXTRA).index(name)) if allo else extra_data(name)
+    want = hip_lines(name, cfg, raw, allo=allo)
+    monkeypatch.setenv("INSTRUCT_ZQ_RESOLVE_P4", "1")
+    assert hip_lines(name, cfg, raw, allo=allo) == want
+
+
 def test_tetraploid_single_workgroup_zq_kernel_gives_the_same_lines(monkeypatch):
     """INSTRUCT_ZQ_COOP=0 selects the one-workgroup update_ZQ kernel (no uniform tape, no hand-offs)"""
     coop = hip_lines("t1")

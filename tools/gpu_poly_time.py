@@ -35,3 +35,4 @@ for it in range(iters):
     print("iter %d %.3fs totallkh %.6e S %s" % (it, time.time() - t, lk, np.round(ch.self_rates(), 3)), flush=True)
 for k, (ms, n) in sorted(ch.profile_results().items(), key=lambda kv: -kv[1][0]):
     print("%-16s %10.3f ms total %6d launches %10.3f ms each" % (k, ms, n, ms / n))
+print("resolve", ch.zq_resolve_stats(), "fallbacks", ch.zq_fallbacks())

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from instruct_amd import capi, synth
+if os.environ.get('ISG_LIB'): capi.LIB_PATH = os.environ['ISG_LIB']
 
 N, L, K, iters = (int(x) for x in (sys.argv[1:5] + ["10000", "5000", "5", "10"][len(sys.argv) - 1:]))
 geno, an, mi = synth.make_diploid(N, L, K)
