@@ -2871,6 +2871,13 @@ static void inbreed_free(isg_ctx *c);
 static void store_free(isg_ctx *c);
 #define NOT_POLY(c, what) if ((c)->poly) return fail(what ": not part of the ploidy 4 chain (poly_geno.c:98-116)")
 
+/* a context under construction: destroyed (device allocations, stream and all) unless construction reaches its end */
+struct CtxGuard {
+	isg_ctx *c;
+	explicit CtxGuard(isg_ctx *p) : c(p) {}
+	~CtxGuard() { if (c) isg_ctx_destroy(c); }
+	void release() { c = nullptr; }
+};
 extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, const int32_t *geno, const int32_t *missindx, isg_ctx **out)
 {
 	*out = nullptr;
@@ -2883,12 +2890,14 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("isg_ctx_create: no HIP device available (the MI355X path has no CPU fallback)");
 	if (cfg->device < 0 || cfg->device >= ndev) return fail("isg_ctx_create: bad device ordinal");
 	HIPCHK(hipSetDevice(cfg->device));
-	isg_ctx *c = new isg_ctx();
+	isg_ctx *c = new isg_ctx(); /* value-initialised: every pointer starts null */
 	c->cfg = *cfg;
+	memset(&c->d, 0, sizeof(c->d));
+	CtxGuard guard(c); /* any early return below releases what has been allocated so far */
 	const int N = cfg->N, L = cfg->L, K = cfg->K;
 	int Amax = 0;
 	for (int j = 0; j < L; j++) Amax = allelenum[j] > Amax ? allelenum[j] : Amax;
-	if (Amax > 254) { delete c; return fail("isg_ctx_create: more than 254 alleles at a locus"); }
+	if (Amax > 254) return fail("isg_ctx_create: more than 254 alleles at a locus");
 	if (Amax < 1) Amax = 1;
 	c->Amax = Amax;
 	const int Lp = (L + 7) & ~7, KP = (K + 1) & ~1;
@@ -2900,7 +2909,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 		for (int j = 0; j < L; j++) {
 			if (missindx[(size_t)i * L + j] == 1 || allelenum[j] <= 1) continue;
 			int a0 = geno[((size_t)i * L + j) * 2], a1 = geno[((size_t)i * L + j) * 2 + 1];
-			if (a0 < 0 || a1 < 0 || a0 >= allelenum[j] || a1 >= allelenum[j]) { delete c; return fail("isg_ctx_create: allele code out of range at a non-missing locus"); }
+			if (a0 < 0 || a1 < 0 || a0 >= allelenum[j] || a1 >= allelenum[j]) return fail("isg_ctx_create: allele code out of range at a non-missing locus");
 			pk[((size_t)i * Lp + j) * 2] = (uint8_t)a0;
 			pk[((size_t)i * Lp + j) * 2 + 1] = (uint8_t)a1;
 			nvalid[i]++;
@@ -2937,7 +2946,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 			DALLOC(d.lftab, double, (size_t)L * Amax * K);
 			const size_t ent = (size_t)50 * L * Amax * Amax * K;
 			if (cfg->mode == 2 && ent * sizeof(double) <= ((size_t)1 << 30)) { DALLOC(d.lltab, double, ent); } /* (mode 3: unclamped initial generations) */
-			if (cfg->mode == 4) { DALLOC(d.lltab, double, ent / 50); } /* one slot: log genofreq_inbreedcoff */
+			if (cfg->mode == 4 && (ent / 50) * sizeof(double) <= ((size_t)1 << 30)) { DALLOC(d.lltab, double, ent / 50); } /* one slot: log genofreq_inbreedcoff */
 		}
 	}
 	c->d_tape = nullptr;
@@ -3025,11 +3034,12 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	c->raw_valid = true;
 	c->prof = false;
 	keyed_layout(c);
-	if (cfg->mode == 0 && !d.lftab) { isg_ctx_destroy(c); return fail("isg_ctx_create: mode 0 needs its log frequency table (INSTRUCT_LL_TABLES must not be 0)"); }
+	if (cfg->mode == 0 && !d.lftab) return fail("isg_ctx_create: mode 0 needs its log frequency table (INSTRUCT_LL_TABLES must not be 0)");
 	if (cfg->mode == 4) {
-		if (!d.lltab) { isg_ctx_destroy(c); return fail("isg_ctx_create: mode 4 needs its log-likelihood table (INSTRUCT_LL_TABLES must not be 0)"); }
-		if (inbreed_alloc(c)) { isg_ctx_destroy(c); return 1; }
+		if (!d.lltab) return fail("isg_ctx_create: mode 4 needs its log-likelihood table (INSTRUCT_LL_TABLES must not be 0; L * Amax^2 * K doubles, at most 1 GiB)");
+		if (inbreed_alloc(c)) return 1;
 	}
+	guard.release();
 	*out = c;
 	return 0;
 }
@@ -3370,6 +3380,7 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 		if (need > c->tape_cap) {
 			if (c->d_tape) HIPCHK(hipFree(c->d_tape));
 			c->d_tape = nullptr;
+			c->tape_cap = 0;
 			HIPCHK(hipMalloc((void **)&c->d_tape, sizeof(double) * need));
 			c->tape_cap = need;
 		}
