@@ -14,7 +14,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "gpurun_out")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 SHORT = [("k_zq_pipe", "k_zq_pipe"), ("k_zq_spec", "k_zq_spec"), ("k_zq_coop", "k_zq_coop"), ("k4_zq_coop", "k4_zq_coop"), ("k_zq<256", "k_zq_keyed"), ("k_zq<512", "k_zq_chain"),
          ("k_loglik<256, true>", "k_loglik_pair"), ("k_loglik<256, false>", "k_loglik_lkh"),
@@ -29,6 +29,9 @@ def short(name):
     return m.group(1) if m else None
 
 
+TOTALS = {}
+
+
 def counter(dirname, cname):
     path = os.path.join(out, dirname, "k_counter_collection.csv")
     acc = defaultdict(list)
@@ -38,6 +41,7 @@ def counter(dirname, cname):
                 s = short(r["Kernel_Name"])
                 if s:
                     acc[s].append(float(r["Counter_Value"]))
+    TOTALS[cname] = {k: (sum(v), len(v)) for k, v in acc.items()}
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
@@ -45,10 +49,21 @@ fetch, write = counter("pmc_fetch", "FETCH_SIZE"), counter("pmc_write", "WRITE_S
 known = 2 * 10000 * 5000 * 2
 factor = known / (fetch["k_count"] * 1024)
 traffic = {k: int(fetch.get(k, 0) * 1024 * factor + write.get(k, 0) * 1024) for k in sorted(set(fetch) | set(write))}
+# the replay schedule's update_ZQ is a phase of launches (k_tapef, one k_zq_block per block of individuals, k_zq_at):
+# its bytes per SWEEP = all those launches' bytes / number of sweeps (= k_zq_at launches)
+if "k_zq_at" in TOTALS["FETCH_SIZE"]:
+    nsweep = TOTALS["FETCH_SIZE"]["k_zq_at"][1]
+    tot = 0.0
+    for k in ("k_tapef", "k_zq_block", "k_zq_at"):
+        tot += TOTALS["FETCH_SIZE"].get(k, (0, 0))[0] * 1024 * factor + TOTALS["WRITE_SIZE"].get(k, (0, 0))[0] * 1024
+    traffic["update_ZQ_replay"] = int(tot / nsweep)
+    traffic["k_zq_block_launches_per_sweep"] = round(TOTALS["FETCH_SIZE"]["k_zq_block"][1] / nsweep, 1)
 detail = {"workload": "config 3 (N=10000 L=5000 K=5 diploid) and config 5 (N=10000 L=20000 K=10 ploidy 4), tools/gpu_prof_driver.py",
           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE calibrated on k_count (reads exactly 200000000 bytes)",
           "raw_KB_per_launch": {k: {"FETCH_SIZE_KB": fetch.get(k), "WRITE_SIZE_KB": write.get(k)} for k in traffic},
-          "fetch_calibration_factor": factor, "hbm_bytes_per_launch": traffic}
+          "fetch_calibration_factor": factor, "hbm_bytes_per_launch": traffic,
+          "calibration_note": "the factor comes from k_count's access pattern (8-byte loads per lane of the diploid byte arrays); the k4_* kernels read 4-byte words and "
+                              "float tables, so their figures are calibrated on a different pattern than their own: read them as estimates"}
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 with open(os.path.join(ROOT, "profiles", f"{rnd}_traffic_detail.json"), "w") as f:
     json.dump(detail, f, indent=1)
