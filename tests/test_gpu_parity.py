@@ -318,6 +318,9 @@ def test_config2_twenty_iterations_bit_exact():
         h.iteration()
         o.iteration()
         _same(h, o, ["z", "count_alleles", "generation", "qq", "self_rates", "alpha", "totallkh", "seeds"], it)
+    # the sweeps really went through the block-wise resolution of the start positions (not its fallback)
+    st = h.zq_resolve_stats()
+    assert h.zq_fallbacks() == 0 and st["blocks"] >= 2000 // 64 and st["launches"] > st["blocks"] and 1 <= st["D"] <= 64
     h.close()
 
 
@@ -332,6 +335,7 @@ def test_config3_two_iterations_bit_exact(full_size):
         h.iteration()
         o.iteration()
         _same(h, o, ["z", "count_alleles", "generation", "qq", "self_rates", "alpha", "totallkh", "seeds"], it)
+    assert h.zq_fallbacks() == 0 and h.zq_resolve_stats()["blocks"] > 100
     h.close()
 
 
