@@ -22,3 +22,15 @@ for n, col in zip(names, d.T):
     q = np.percentile(col, [5, 50, 95])
     print(f"{n:22s} mean {col.mean():9.0f} ticks   pct 5/50/95: " + " ".join("%7.0f" % x for x in q))
 print("total", (s[:, 7] - s[:, 0]).mean(), "launch to launch", np.diff(s[:, 0]).mean())
+
+u = buf[2048:2048 + 247].astype(np.int64)   # launch 50: all units, all stage stamps (stamp 1 unused)
+st = u[:, [0, 2, 3, 4, 5, 6, 7]]
+has = u[:, 1] > u[:, 4]
+print("units with a noted draw handled by thread 0: %d of %d; loop end -> rows loaded: median %d ; rows loaded -> barrier after: median %d" % (
+    has.sum(), len(u), np.median((u[:, 1] - u[:, 4])[has]) if has.any() else -1, np.median((u[:, 5] - u[:, 1])[has]) if has.any() else -1))
+dd = np.diff(st, axis=1)
+tot = st[:, -1] - st[:, 0]
+order = np.argsort(tot)
+print("launch 50, per unit (cycles): total pct 5/50/95/max", [int(x) for x in np.percentile(tot, [5, 50, 95, 100])])
+for n, col in zip(["start+walk", "header", "loop", "events+barriers", "dirichlet", "publish"], dd.T):
+    print("  %-16s median %7d  p95 %7d  max %7d   in the 5 slowest units: %s" % (n, np.median(col), np.percentile(col, 95), col.max(), [int(x) for x in col[order[-5:]]]))
