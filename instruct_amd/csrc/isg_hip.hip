@@ -31,7 +31,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <array>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/instruct_hip.h"
 #include "isg_math.h"
@@ -140,6 +142,8 @@ struct isg_ctx {
 	unsigned long long *d_pipe = nullptr; /* its granules (one line per publishing wave) */
 	unsigned long long *d_spop = nullptr; /* k_spop_tree: limbs of the 2^K exact sums */
 	std::vector<double> htape;            /* replay update_P: the host loop's uniforms (host_tape_begin) */
+	std::vector<double> pshape;           /* ... the shapes of its gammas in stream order ... */
+	std::vector<std::array<double, 5>> pcoef; /* ... and rgamma2's shape-only constants (HostGammaCoef) */
 	uint64_t htape_len = 0;
 	int host_tape = 1;                    /* INSTRUCT_HOST_TAPE=0: the host loop steps the generator itself */
 	int spop_tree = 1;                    /* INSTRUCT_SPOP_TREE=0: the one-workgroup k_spop always */
@@ -2782,6 +2786,69 @@ static inline double host_rgamma2_try(isg_cursor *c, double alpha)
 	}
 	return c1 * w;
 }
+/* rgamma2's constants only depend on the shape (random.c:199-203): the sequential loop has three divisions and a square root
+ * less per attempt when they are formed beforehand -- for all gammas of the sweep at once, by a few threads (the shapes are
+ * the counts + 1, known before the first draw).  Same expressions, same values. */
+struct HostGammaCoef { double c1, c2, c3, c4, c5; };
+static inline void host_gamma_coef(double alpha, HostGammaCoef *o)
+{
+	o->c1 = alpha - 1;
+	o->c2 = (alpha - 1 / (6 * alpha)) / o->c1;
+	o->c3 = 2 / o->c1;
+	o->c4 = o->c3 + 2;
+	o->c5 = 1 / isg_sqrt(alpha);
+}
+static void host_gamma_coefs(const double *shape, size_t n, HostGammaCoef *out)
+{
+	unsigned nt = std::thread::hardware_concurrency();
+	nt = nt > 4 ? 4 : (nt < 1 ? 1 : nt);
+	if (n < 65536) nt = 1;
+	auto work = [&](size_t a, size_t b) { for (size_t g = a; g < b; g++) host_gamma_coef(shape[g], &out[g]); };
+	std::vector<std::thread> th;
+	const size_t per = (n + nt - 1) / nt;
+	for (unsigned k = 1; k < nt; k++) th.emplace_back(work, k * per < n ? k * per : n, (k + 1) * per < n ? (k + 1) * per : n);
+	work(0, per < n ? per : n);
+	for (auto &t : th) t.join();
+}
+static inline double host_rgamma2_try_pre(isg_cursor *c, double alpha, const HostGammaCoef &k)
+{
+	double u1, u2, w;
+	do {
+		u1 = isg_cur_next(c);
+		u2 = isg_cur_next(c);
+		if (alpha > 2.5) u1 = u2 + k.c5 * (1 - 1.86 * u1);
+	} while ((u1 >= 1) || (u1 <= 0));
+	w = k.c2 * u2 / u1;
+	if ((k.c3 * u1 + w + 1 / w) > k.c4) {
+		const float l1 = logf((float)u1), lw = logf((float)w);
+		const double al1 = fabs((double)l1), alw = fabs((double)lw);
+		const double dlt = (k.c3 * (double)l1 - (double)lw + w) - 1;
+		const double tol = 2e-6 * (fabs(k.c3) * (1.0 + al1) + 1.0 + alw) + 1e-12 * fabs(w);
+		bool rej;
+		if (dlt > tol) rej = true;
+		else if (dlt < -tol) rej = false;
+		else rej = (k.c3 * isg_log(u1) - isg_log(w) + w) >= 1;
+		if (rej) return -1;
+	}
+	return k.c1 * w;
+}
+/* rdirich over shapes given directly (count + 1 already formed) with their constants */
+static void host_rdirich_pre(isg_cursor *c, const double *shape, const HostGammaCoef *coef, int n, double *out)
+{
+	double sum = 0;
+	for (int k = 0; k < n; k++) {
+		const double a = shape[k];
+		double g = 0;
+		if (a > 1) {
+			do { g = host_rgamma2_try_pre(c, a, coef[k]); } while (g < 0);
+		} else {
+			g = isg_rgamma(c, a);
+		}
+		out[k] = g;
+		sum += g;
+	}
+	for (int k = 0; k < n; k++) out[k] /= sum;
+}
 static void host_rdirich(isg_cursor *c, const double *count, int n, double *out, double add)
 {
 	double sum = 0;
@@ -3244,15 +3311,30 @@ extern "C" int isg_update_P(isg_ctx *c)
 	if (host_tape_begin(c, ngamma, &cur)) return 1;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	host_tape_attach(c, &cur);
-	std::vector<double> tmp(A);
-	for (int k = 0; k < K; k++)
-		for (int j = 0; j < L; j++) {
-			int Aj = c->allelenum[j];
-			if (Aj <= 1) continue;
-			for (int a = 0; a < Aj; a++) tmp[a] = (double)c->cnt_h[((size_t)j * A + a) * K + k];
-			host_tape_guard(c, &cur, Aj);
-			host_rdirich(&cur, tmp.data(), Aj, &c->freq[((size_t)k * L + j) * A], 1.0);
-		}
+	/* the shapes (count + 1.0, rdirich's `add`) of all gammas in stream order and their constants, then the draws */
+	c->pshape.resize(ngamma);
+	c->pcoef.resize(ngamma);
+	{
+		size_t g = 0;
+		for (int k = 0; k < K; k++)
+			for (int j = 0; j < L; j++) {
+				const int Aj = c->allelenum[j];
+				if (Aj <= 1) continue;
+				for (int a = 0; a < Aj; a++) c->pshape[g++] = (double)c->cnt_h[((size_t)j * A + a) * K + k] + 1.0;
+			}
+	}
+	host_gamma_coefs(c->pshape.data(), (size_t)ngamma, (HostGammaCoef *)c->pcoef.data());
+	{
+		size_t g = 0;
+		for (int k = 0; k < K; k++)
+			for (int j = 0; j < L; j++) {
+				const int Aj = c->allelenum[j];
+				if (Aj <= 1) continue;
+				host_tape_guard(c, &cur, Aj);
+				host_rdirich_pre(&cur, &c->pshape[g], (const HostGammaCoef *)c->pcoef.data() + g, Aj, &c->freq[((size_t)k * L + j) * A]);
+				g += (size_t)Aj;
+			}
+	}
 	host_tape_end(c, &cur);
 	return upload_freq(c);
 }
