@@ -71,9 +71,11 @@ def timed_steps(chain, steps, warmup, world):
     return dt, lk, prof
 
 
-# the replay schedule's update_ZQ is a PHASE of kernels: the uniforms as floats, one k_zq_block launch per block of individuals
-# (start positions), then the sweep at the resolved positions.  Its roofline entry is the phase: 2 N L P bytes / phase time.
-ZQ_RESOLVE = ("k_tapef", "k_zq_block", "k_zq_at")
+# the replay schedule's update_ZQ is a PHASE of kernels: the uniforms as floats, the resolution of the start positions block by block
+# (k_zq_blocks: one launch, all blocks; k_zq_block: one launch per block when the workgroups cannot all be resident), then the
+# sweep at the resolved positions.  Its roofline entry is the phase: 2 N L P bytes / phase time.
+ZQ_RESOLVE = ("k_tapef", "k_zq_blocks", "k_zq_at")
+ZQ_RESOLVE_PER_BLOCK = ("k_tapef", "k_zq_block", "k_zq_at")
 
 
 def roofline(prof, kernel, bytes_per_launch, traffic):
@@ -295,8 +297,10 @@ def main():
         dt, lk, prof = timed_steps(ch, args.steps, args.warmup, world)
         if sched != capi.SCHED_REPLAY:
             zq = "k_zq_keyed"
-        elif "k_zq_block" in prof:
+        elif "k_zq_blocks" in prof:
             zq = ZQ_RESOLVE
+        elif "k_zq_block" in prof:
+            zq = ZQ_RESOLVE_PER_BLOCK
         else:
             zq = next(k for k in ("k_zq_pipe", "k_zq_spec", "k_zq_coop", "k_zq_chain") if k in prof)
         # update_ZQ: reads the genotype byte and writes the Z byte of every allele copy

@@ -703,6 +703,8 @@ __device__ __forceinline__ double weights(const double *__restrict__ F, const do
 #ifdef ISG_STAMPS
 __device__ unsigned long long g_stamps[4096 * 8];
 #define STAMP(i, k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && (i) < 4096) g_stamps[(i) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long g_stamps2[2048 * 8]; /* sub-stages of the resolver's walk (STAMPW) */
+extern "C" int isg_diag_stamps2(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * 2048 * 8); }
 extern "C" int isg_diag_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 4096 * 8); }
 #else
 #define STAMP(i, k) do { } while (0)
@@ -2915,6 +2917,16 @@ static void host_tape_end(isg_ctx *c, isg_cursor *cur)
 
 extern "C" const char *isg_last_error(void) { return g_err.c_str(); }
 
+/* The cooperative replay kernels hand data between workgroups by polling, so every workgroup of the launch must be
+ * resident at the same time: `blocks` of `threads` threads have to fit on the device's CUs at this kernel's occupancy. */
+template <class Kern>
+static bool fits_resident(Kern kern, int threads, long blocks, int device)
+{
+	int per_cu = 0, cus = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0) != hipSuccess) return false;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
+	return (long)per_cu * cus >= blocks;
+}
 #include "isg_resolve_hip.inc"
 
 /* ploidy 4 (isg_poly_hip.inc, included further down) */
@@ -3408,16 +3420,6 @@ extern "C" int isg_update_G(isg_ctx *c)
 }
 
 /* ---- update_ZQ ---- */
-/* The cooperative replay kernels hand data between workgroups by polling, so every workgroup of the launch must be
- * resident at the same time: `blocks` of `threads` threads have to fit on the device's CUs at this kernel's occupancy. */
-template <class Kern>
-static bool fits_resident(Kern kern, int threads, long blocks, int device)
-{
-	int per_cu = 0, cus = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0) != hipSuccess) return false;
-	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
-	return (long)per_cu * cus >= blocks;
-}
 /* A cooperative sweep that did not complete (a hand-off timed out because the GPU is shared and a workgroup was not
  * scheduled, or an individual's Dirichlet ran past the uniform tape) has overwritten part of Z, qq and qqnum.  Z and qqnum
  * are outputs only; qq is restored from the copy taken before the launch and the sweep is redone from the same stream

@@ -1,4 +1,4 @@
-"""Diagnostic: cycle stamps inside k_zq_block (ISG_STAMPS build) for one unit, per launch."""
+"""Diagnostic: cycle stamps inside k_zq_blocks (ISG_STAMPS build): one unit over many blocks, all units of one block."""
 import os, sys, subprocess, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,21 +16,30 @@ print(h.zq_resolve_stats())
 buf = np.zeros((4096, 8), dtype=np.uint64)
 h.lib.isg_diag_stamps(buf.ctypes.data_as(C.c_void_p))
 s = buf[20:300].astype(np.int64)
-names = ["start->tables", "->walk done", "->header loads", "->loci loop", "->reduce barrier", "->dirichlet", "->publish"]
+names = ["start->granules in", "->walk done", "->header loads", "->loci loop", "->noted draws", "->dirichlet", "->publish"]
 d = np.diff(s, axis=1)
 for n, col in zip(names, d.T):
     q = np.percentile(col, [5, 50, 95])
     print(f"{n:22s} mean {col.mean():9.0f} ticks   pct 5/50/95: " + " ".join("%7.0f" % x for x in q))
-print("total", (s[:, 7] - s[:, 0]).mean(), "launch to launch", np.diff(s[:, 0]).mean())
+print("total", (s[:, 7] - s[:, 0]).mean(), "block to block", np.diff(s[:, 0]).mean())
 
-u = buf[2048:2048 + 247].astype(np.int64)   # launch 50: all units, all stage stamps (stamp 1 unused)
-st = u[:, [0, 2, 3, 4, 5, 6, 7]]
-has = u[:, 1] > u[:, 4]
-print("units with a noted draw handled by thread 0: %d of %d; loop end -> rows loaded: median %d ; rows loaded -> barrier after: median %d" % (
-    has.sum(), len(u), np.median((u[:, 1] - u[:, 4])[has]) if has.any() else -1, np.median((u[:, 5] - u[:, 1])[has]) if has.any() else -1))
-dd = np.diff(st, axis=1)
-tot = st[:, -1] - st[:, 0]
+u = buf[2048:2048 + 247].astype(np.int64)   # block 50: all units, all stage stamps
+dd = np.diff(u, axis=1)
+tot = u[:, -1] - u[:, 0]
 order = np.argsort(tot)
-print("launch 50, per unit (cycles): total pct 5/50/95/max", [int(x) for x in np.percentile(tot, [5, 50, 95, 100])])
-for n, col in zip(["start+walk", "header", "loop", "events+barriers", "dirichlet", "publish"], dd.T):
-    print("  %-16s median %7d  p95 %7d  max %7d   in the 5 slowest units: %s" % (n, np.median(col), np.percentile(col, 95), col.max(), [int(x) for x in col[order[-5:]]]))
+print("block 50, per unit (cycles): total pct 5/50/95/max", [int(x) for x in np.percentile(tot, [5, 50, 95, 100])])
+for n, col in zip(["wait for granules", "walk", "header", "loop", "noted draws", "dirichlet", "publish"], dd.T):
+    print("  %-18s median %7d  p95 %7d  max %7d   in the 5 slowest units: %s" % (n, np.median(col), np.percentile(col, 95), col.max(), [int(x) for x in col[order[-5:]]]))
+work = u[:, 7] - u[:, 1]
+print("  work (granules in -> publish): median %d p95 %d max %d" % (np.median(work), np.percentile(work, 95), work.max()))
+
+b2 = np.zeros((2048, 8), dtype=np.uint64)
+if hasattr(h.lib, "isg_diag_stamps2"):
+    h.lib.isg_diag_stamps2(b2.ctypes.data_as(C.c_void_p))
+    w = b2[20:300, :5].astype(np.int64)
+    g_in = buf[20:300, 1].astype(np.int64)
+    done = buf[20:300, 2].astype(np.int64)
+    cols = np.column_stack([g_in, w, done])
+    dw = np.diff(cols, axis=1)
+    for n, col in zip(["granules in -> table in LDS", "-> (d0, E) read", "-> rows in registers", "-> walk", "-> results in LDS", "-> barrier"], dw.T):
+        print("  walk stage %-28s median %6d  p5 %6d p95 %6d" % (n, np.median(col), np.percentile(col, 5), np.percentile(col, 95)))
