@@ -12,7 +12,8 @@ h = capi.HipChain(geno, an, mi, K)
 h.setseeds(13, 4, 1972)
 h.chain_init(np.array([h.ran1() for _ in range(K)], dtype=np.float32))
 h.iteration(); h.iteration()
-print(h.zq_resolve_stats())
+rst = h.zq_resolve_stats()
+print(rst)
 buf = np.zeros((4096, 8), dtype=np.uint64)
 h.lib.isg_diag_stamps(buf.ctypes.data_as(C.c_void_p))
 s = buf[20:300].astype(np.int64)
@@ -23,7 +24,7 @@ for n, col in zip(names, d.T):
     print(f"{n:22s} mean {col.mean():9.0f} ticks   pct 5/50/95: " + " ".join("%7.0f" % x for x in q))
 print("total", (s[:, 7] - s[:, 0]).mean(), "block to block", np.diff(s[:, 0]).mean())
 
-u = buf[2048:2048 + 247].astype(np.int64)   # block 50: all units, all stage stamps
+u = buf[2048:2048 + rst['units']].astype(np.int64)   # block 50: all units, all stage stamps
 dd = np.diff(u, axis=1)
 tot = u[:, -1] - u[:, 0]
 order = np.argsort(tot)
@@ -43,3 +44,7 @@ if hasattr(h.lib, "isg_diag_stamps2"):
     dw = np.diff(cols, axis=1)
     for n, col in zip(["granules in -> table in LDS", "-> (d0, E) read", "-> rows in registers", "-> walk", "-> results in LDS", "-> barrier"], dw.T):
         print("  walk stage %-28s median %6d  p5 %6d p95 %6d" % (n, np.median(col), np.percentile(col, 5), np.percentile(col, 95)))
+    if b2[20:300, 5].any():
+        warm = buf[20:300, 4].astype(np.int64) - b2[20:300, 5].astype(np.int64)
+        cold = b2[20:300, 5].astype(np.int64) - buf[20:300, 3].astype(np.int64)
+        print("  ISG_LOOP_TWICE: simple cold loop median %d, pipelined loop on warm caches median %d p5 %d p95 %d" % (np.median(cold), np.median(warm), np.percentile(warm, 5), np.percentile(warm, 95)))
