@@ -49,15 +49,17 @@ fetch, write = counter("pmc_fetch", "FETCH_SIZE"), counter("pmc_write", "WRITE_S
 known = 2 * 10000 * 5000 * 2
 factor = known / (fetch["k_count"] * 1024)
 traffic = {k: int(fetch.get(k, 0) * 1024 * factor + write.get(k, 0) * 1024) for k in sorted(set(fetch) | set(write))}
-# the replay schedule's update_ZQ is a phase of launches (k_tapef, one k_zq_block per block of individuals, k_zq_at):
-# its bytes per SWEEP = all those launches' bytes / number of sweeps (= k_zq_at launches)
+# the replay schedule's update_ZQ is a phase of launches (k_tapef, the block resolution -- k_zq_blocks: one launch for all blocks, or
+# k_zq_block: one per block --, k_zq_at): its bytes per SWEEP = all those launches' bytes / number of sweeps (= k_zq_at launches)
 if "k_zq_at" in TOTALS["FETCH_SIZE"]:
     nsweep = TOTALS["FETCH_SIZE"]["k_zq_at"][1]
     tot = 0.0
-    for k in ("k_tapef", "k_zq_block", "k_zq_at"):
+    for k in ("k_tapef", "k_zq_blocks", "k_zq_block", "k_zq_at"):
         tot += TOTALS["FETCH_SIZE"].get(k, (0, 0))[0] * 1024 * factor + TOTALS["WRITE_SIZE"].get(k, (0, 0))[0] * 1024
     traffic["update_ZQ_replay"] = int(tot / nsweep)
-    traffic["k_zq_block_launches_per_sweep"] = round(TOTALS["FETCH_SIZE"]["k_zq_block"][1] / nsweep, 1)
+    for k in ("k_zq_blocks", "k_zq_block"):
+        if k in TOTALS["FETCH_SIZE"]:
+            traffic[k + "_launches_per_sweep"] = round(TOTALS["FETCH_SIZE"][k][1] / nsweep, 1)
 detail = {"workload": "config 3 (N=10000 L=5000 K=5 diploid) and config 5 (N=10000 L=20000 K=10 ploidy 4), tools/gpu_prof_driver.py",
           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE calibrated on k_count (reads exactly 200000000 bytes)",
           "raw_KB_per_launch": {k: {"FETCH_SIZE_KB": fetch.get(k), "WRITE_SIZE_KB": write.get(k)} for k in traffic},
