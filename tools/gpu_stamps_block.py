@@ -16,7 +16,8 @@ rst = h.zq_resolve_stats()
 print(rst)
 buf = np.zeros((4096, 8), dtype=np.uint64)
 h.lib.isg_diag_stamps(buf.ctypes.data_as(C.c_void_p))
-s = buf[20:300].astype(np.int64)
+nb = min(300, rst['blocks'] - 2)
+s = buf[20:nb].astype(np.int64)
 names = ["start->granules in", "->walk done", "->header loads", "->loci loop", "->noted draws", "->dirichlet", "->publish"]
 d = np.diff(s, axis=1)
 for n, col in zip(names, d.T):
@@ -37,14 +38,22 @@ print("  work (granules in -> publish): median %d p95 %d max %d" % (np.median(wo
 b2 = np.zeros((2048, 8), dtype=np.uint64)
 if hasattr(h.lib, "isg_diag_stamps2"):
     h.lib.isg_diag_stamps2(b2.ctypes.data_as(C.c_void_p))
-    w = b2[20:300, :5].astype(np.int64)
-    g_in = buf[20:300, 1].astype(np.int64)
-    done = buf[20:300, 2].astype(np.int64)
+    w = b2[20:nb, :5].astype(np.int64)
+    g_in = buf[20:nb, 1].astype(np.int64)
+    done = buf[20:nb, 2].astype(np.int64)
     cols = np.column_stack([g_in, w, done])
     dw = np.diff(cols, axis=1)
     for n, col in zip(["granules in -> table in LDS", "-> (d0, E) read", "-> rows in registers", "-> walk", "-> results in LDS", "-> barrier"], dw.T):
         print("  walk stage %-28s median %6d  p5 %6d p95 %6d" % (n, np.median(col), np.percentile(col, 5), np.percentile(col, 95)))
-    if b2[20:300, 5].any():
-        warm = buf[20:300, 4].astype(np.int64) - b2[20:300, 5].astype(np.int64)
-        cold = b2[20:300, 5].astype(np.int64) - buf[20:300, 3].astype(np.int64)
+    if b2[20:nb, 5].any():
+        warm = buf[20:nb, 4].astype(np.int64) - b2[20:nb, 5].astype(np.int64)
+        cold = b2[20:nb, 5].astype(np.int64) - buf[20:nb, 3].astype(np.int64)
         print("  ISG_LOOP_TWICE: simple cold loop median %d, pipelined loop on warm caches median %d p5 %d p95 %d" % (np.median(cold), np.median(warm), np.percentile(warm, 5), np.percentile(warm, 95)))
+
+# where the slow units of block 50 are: by XCD (blockIdx % 8) and by position in the XCD's share
+lp = (u[:, 4] - u[:, 3])
+print("loop cycles of block 50 by XCD (blockIdx % 8):", [int(np.median(lp[x::8])) for x in range(8)])
+idx = np.arange(len(lp)) // 8
+print("loop cycles by position in the XCD's share (eighths):", [int(np.median(lp[(idx * 8 // (idx.max() + 1)) == k])) for k in range(8)])
+st0 = u[:, 1] - u[:, 1].min()
+print("granules-in time skew across units: median %d p95 %d max %d" % (np.median(st0), np.percentile(st0, 95), st0.max()))
