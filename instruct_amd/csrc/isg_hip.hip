@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <array>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -141,6 +142,7 @@ struct isg_ctx {
 	int pipe_xcd; /* 1: its workgroups on one XCD when they fit (INSTRUCT_ZQ_PIPE_XCD=0 disables) */
 	unsigned long long *d_pipe = nullptr; /* its granules (one line per publishing wave) */
 	unsigned long long *d_spop = nullptr; /* k_spop_tree: limbs of the 2^K exact sums */
+	bool counted = false;                 /* in g_live_ctx */
 	std::vector<double> htape;            /* replay update_P: the host loop's uniforms (host_tape_begin) */
 	std::vector<double> pshape;           /* ... the shapes of its gammas in stream order ... */
 	std::vector<std::array<double, 5>> pcoef; /* ... and rgamma2's shape-only constants (HostGammaCoef) */
@@ -2927,7 +2929,18 @@ static bool fits_resident(Kern kern, int threads, long blocks, int device)
 	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
 	return (long)per_cu * cus >= blocks;
 }
+/* contexts alive per device in THIS process: the one-launch block resolver wants the whole chip to itself (all its workgroups
+ * resident); with several chains on one GPU the per-block launches interleave much better (8 chains at config 3: 72 vs 179
+ * chain-iterations/s), so it is only used by a device's sole context */
+static std::atomic<int> g_live_ctx[64];
+static void ctx_count(isg_ctx *c, int delta);
 #include "isg_resolve_hip.inc"
+static void ctx_count(isg_ctx *c, int delta)
+{
+	if (c->cfg.device < 0 || c->cfg.device >= 64) return;
+	if (delta > 0 && !c->counted) { g_live_ctx[c->cfg.device].fetch_add(1); c->counted = true; }
+	if (delta < 0 && c->counted) { g_live_ctx[c->cfg.device].fetch_sub(1); c->counted = false; }
+}
 
 /* ploidy 4 (isg_poly_hip.inc, included further down) */
 static int poly_ctx_create(const isg_config *cfg, const int32_t *allelenum, const int32_t *seq, isg_ctx **out);
@@ -2971,6 +2984,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	HIPCHK(hipSetDevice(cfg->device));
 	isg_ctx *c = new isg_ctx(); /* value-initialised: every pointer starts null */
 	c->cfg = *cfg;
+	ctx_count(c, +1);
 	memset(&c->d, 0, sizeof(c->d));
 	CtxGuard guard(c); /* any early return below releases what has been allocated so far */
 	const int N = cfg->N, L = cfg->L, K = cfg->K;
@@ -3126,6 +3140,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 extern "C" void isg_ctx_destroy(isg_ctx *c)
 {
 	if (!c) return;
+	ctx_count(c, -1);
 	(void)hipSetDevice(c->cfg.device);
 	(void)hipStreamSynchronize(c->stream);
 	store_free(c);

@@ -106,7 +106,7 @@ typedef struct {
 	char out[4096], log[4096], cf[4096];
 } worker;
 
-static pid_t spawn(const char *exe, char **argv, const char *logpath, int device, int rank, int world, const char *dir, const char *gather)
+static pid_t spawn(const char *exe, char **argv, const char *logpath, int device, int rank, int world, const char *dir, const char *gather, int shared_gpu)
 {
 	pid_t pid = fork();
 	if (pid < 0) die("fork failed", NULL);
@@ -116,6 +116,9 @@ static pid_t spawn(const char *exe, char **argv, const char *logpath, int device
 		dup2(fileno(stdout), fileno(stderr));
 		snprintf(buf, sizeof(buf), "%d", device);
 		setenv("INSTRUCT_DEVICE", buf, 1);
+		/* more workers than GPUs: the replay update_ZQ resolver launches block by block (its one-launch form wants the whole chip
+		 * to itself; processes cannot see each other's contexts) -- unless the caller has set the switch */
+		if (shared_gpu) setenv("INSTRUCT_ZQ_RESOLVE_PERSIST", "0", 0);
 		if (world > 0) {
 			snprintf(buf, sizeof(buf), "%d", rank);
 			setenv("INSTRUCT_MGPU_RANK", buf, 1);
@@ -213,7 +216,7 @@ int main(int argc, char **argv)
 			av[n++] = "-cf"; av[n++] = w[r].cf;
 		}
 		av[n] = NULL;
-		w[r].pid = spawn(exe, av, w[r].log, r % gpus, r, inf_K == 1 ? 0 : W, dir, gather);
+		w[r].pid = spawn(exe, av, w[r].log, r % gpus, r, inf_K == 1 ? 0 : W, dir, gather, W > gpus);
 		free(av);
 	}
 	for (r = 0; r < W; r++) {
