@@ -143,7 +143,9 @@ struct isg_ctx {
 	unsigned long long *d_pipe = nullptr; /* its granules (one line per publishing wave) */
 	unsigned long long *d_spop = nullptr; /* k_spop_tree: limbs of the 2^K exact sums */
 	bool counted = false;                 /* in g_live_ctx */
-	std::vector<double> htape;            /* replay update_P: the host loop's uniforms (host_tape_begin) */
+	hipEvent_t ev_cnt = nullptr;          /* replay update_P: the counts have arrived (the tape is still on its way) */
+	double *htape = nullptr;              /* replay update_P: the host loop's uniforms (host_tape_begin); pinned: a 2 MB copy per sweep */
+	uint64_t htape_cap = 0;
 	std::vector<double> pshape;           /* ... the shapes of its gammas in stream order ... */
 	std::vector<std::array<double, 5>> pcoef; /* ... and rgamma2's shape-only constants (HostGammaCoef) */
 	uint64_t htape_len = 0;
@@ -2806,7 +2808,7 @@ static void host_gamma_coefs(const double *shape, size_t n, HostGammaCoef *out)
 {
 	unsigned nt = std::thread::hardware_concurrency();
 	nt = nt > 4 ? 4 : (nt < 1 ? 1 : nt);
-	if (n < 65536) nt = 1;
+	if (n < 16384) nt = 1;
 	auto work = [&](size_t a, size_t b) { for (size_t g = a; g < b; g++) host_gamma_coef(shape[g], &out[g]); };
 	std::vector<std::thread> th;
 	const size_t per = (n + nt - 1) / nt;
@@ -2892,17 +2894,36 @@ static int host_tape_begin(isg_ctx *c, uint64_t ngamma, isg_cursor *cur)
 		HIPCHK(hipMalloc((void **)&c->d_tape, sizeof(double) * need));
 		c->tape_cap = need;
 	}
-	if (c->htape.size() < need) c->htape.resize(need);
+	if (c->htape_cap < need) {
+		if (c->htape) (void)hipHostFree(c->htape);
+		c->htape = nullptr;
+		c->htape_cap = 0;
+		HIPCHK(hipHostMalloc((void **)&c->htape, sizeof(double) * need, hipHostMallocDefault));
+		c->htape_cap = need;
+	}
 	prof_begin(c);
 	hipLaunchKernelGGL(k_tape, dim3((unsigned)((need + 2047) / 2048)), dim3(256), 0, c->stream, c->d.tab, c->rng, (unsigned long long)need, c->d_tape);
 	prof_end(c, "k_tape_host");
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpyAsync(c->htape.data(), c->d_tape, sizeof(double) * need, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(c->htape, c->d_tape, sizeof(double) * need, hipMemcpyDeviceToHost, c->stream));
 	c->htape_len = need;
 	return 0;
 }
+/* replay update_P: marks / waits for the point of the stream where the counts' copy ends, so that the host can form the shapes and
+ * their constants while the uniform tape is generated and copied */
+static int counts_mark(isg_ctx *c)
+{
+	if (!c->ev_cnt) HIPCHK(hipEventCreateWithFlags(&c->ev_cnt, hipEventDisableTiming));
+	HIPCHK(hipEventRecord(c->ev_cnt, c->stream));
+	return 0;
+}
+static int counts_wait(isg_ctx *c)
+{
+	HIPCHK(hipEventSynchronize(c->ev_cnt));
+	return 0;
+}
 /* call after the stream has been synchronised, before the loop */
-static void host_tape_attach(isg_ctx *c, isg_cursor *cur) { if (c->htape_len) cur->tape = c->htape.data(); }
+static void host_tape_attach(isg_ctx *c, isg_cursor *cur) { if (c->htape_len) cur->tape = c->htape; }
 /* before each Dirichlet of n gammas: leave the tape while a comfortable margin remains (32 attempts per gamma) */
 static inline void host_tape_guard(isg_ctx *c, isg_cursor *cur, int n)
 {
@@ -3143,6 +3164,10 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	ctx_count(c, -1);
 	(void)hipSetDevice(c->cfg.device);
 	(void)hipStreamSynchronize(c->stream);
+	if (c->htape) (void)hipHostFree(c->htape);
+	c->htape = nullptr;
+	if (c->ev_cnt) (void)hipEventDestroy(c->ev_cnt);
+	c->ev_cnt = nullptr;
 	store_free(c);
 	resolve_free(c);
 	if (c->poly) {
@@ -3332,12 +3357,12 @@ extern "C" int isg_update_P(isg_ctx *c)
 	/* replay: the K*L Dirichlets consume the stream in (k, j) order with data-dependent length
 	 * (random.c:167-250), so they are drawn sequentially on the host from the counts */
 	HIPCHK(hipMemcpyAsync(c->cnt_h.data(), d.cnt, sizeof(int) * c->cnt_h.size(), hipMemcpyDeviceToHost, c->stream));
+	if (counts_mark(c)) return 1;
 	isg_cursor cur;
 	uint64_t ngamma = 0;
 	for (int j = 0; j < L; j++) ngamma += (c->allelenum[j] > 1) ? (uint64_t)c->allelenum[j] * K : 0;
 	if (host_tape_begin(c, ngamma, &cur)) return 1;
-	HIPCHK(hipStreamSynchronize(c->stream));
-	host_tape_attach(c, &cur);
+	if (counts_wait(c)) return 1;
 	/* the shapes (count + 1.0, rdirich's `add`) of all gammas in stream order and their constants, then the draws */
 	c->pshape.resize(ngamma);
 	c->pcoef.resize(ngamma);
@@ -3351,6 +3376,8 @@ extern "C" int isg_update_P(isg_ctx *c)
 			}
 	}
 	host_gamma_coefs(c->pshape.data(), (size_t)ngamma, (HostGammaCoef *)c->pcoef.data());
+	HIPCHK(hipStreamSynchronize(c->stream)); /* the tape */
+	host_tape_attach(c, &cur);
 	{
 		size_t g = 0;
 		for (int k = 0; k < K; k++)
