@@ -143,6 +143,7 @@ struct isg_ctx {
 	unsigned long long *d_pipe = nullptr; /* its granules (one line per publishing wave) */
 	unsigned long long *d_spop = nullptr; /* k_spop_tree: limbs of the 2^K exact sums */
 	bool counted = false;                 /* in g_live_ctx */
+	std::vector<void *> pinned;           /* host vectors registered with the runtime (pin_host): the per-sweep copies of update_P */
 	hipEvent_t ev_cnt = nullptr;          /* replay update_P: the counts have arrived (the tape is still on its way) */
 	double *htape = nullptr;              /* replay update_P: the host loop's uniforms (host_tape_begin); pinned: a 2 MB copy per sweep */
 	uint64_t htape_cap = 0;
@@ -2909,6 +2910,13 @@ static int host_tape_begin(isg_ctx *c, uint64_t ngamma, isg_cursor *cur)
 	c->htape_len = need;
 	return 0;
 }
+/* The per-sweep host copies of replay update_P (counts down, frequencies up) go through vectors of fixed size: registered with the
+ * runtime they are copied by DMA at PCIe rate instead of through a staging buffer.  Failure to register only costs that speed. */
+static void pin_host(isg_ctx *c, void *ptr, size_t bytes)
+{
+	if (ptr && bytes && hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) c->pinned.push_back(ptr);
+	else (void)hipGetLastError();
+}
 /* replay update_P: marks / waits for the point of the stream where the counts' copy ends, so that the host can form the shapes and
  * their constants while the uniform tape is generated and copied */
 static int counts_mark(isg_ctx *c)
@@ -3139,6 +3147,8 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	c->state.assign(K, 0);
 	c->indvlkh.assign(N, 0.0);
 	c->cnt_h.assign((size_t)L * Amax * K, 0);
+	pin_host(c, c->cnt_h.data(), sizeof(int) * c->cnt_h.size());
+	pin_host(c, c->freq_stage.data(), sizeof(double) * c->freq_stage.size());
 	c->alpha = 0;
 	c->totallkh = 0;
 	c->iter = 0;
@@ -3168,6 +3178,8 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	c->htape = nullptr;
 	if (c->ev_cnt) (void)hipEventDestroy(c->ev_cnt);
 	c->ev_cnt = nullptr;
+	for (void *q : c->pinned) (void)hipHostUnregister(q);
+	c->pinned.clear();
 	store_free(c);
 	resolve_free(c);
 	if (c->poly) {
