@@ -173,6 +173,12 @@ long isg_zq_fallbacks(isg_ctx *ctx);
  * out = {blocks, blocks ended early by a window miss, kernel launches, individuals per block, units per block, 1000 mu,
  * 1000 sigma, draws redone exactly (diagnostic builds)} */
 int isg_zq_resolve_stats(isg_ctx *ctx, long out[8]);
+/* Host only (no device needed): the resolver's plan for `units` workgroups per block given the rejection statistics (mu, sigma: mean and
+ * spread of a Dirichlet's rejected attempts) and the window parameters (a: half-width in sigma, shape: taper along the block).
+ * lo, w: per individual of the block its first candidate and number of candidates; ur, uo, cslot: per unit its individual, first
+ * candidate and slot in the walk's table image (arrays of 64 / 64 / 512 / 512 / 512 shorts).  Returns individuals per block, *nunits =
+ * units used.  For tests of the plan's invariants. */
+int isg_zq_resolve_plan(int units, double mu, double sigma, double a, double shape, short *lo, short *w, short *ur, short *uo, short *cslot, int *nunits);
 
 /* per-kernel device timing with HIP events on the launch stream (bench.py roofline) */
 int isg_profile_enable(isg_ctx *ctx, int on);

@@ -24,7 +24,7 @@ EXPORTS = [
     "isg_get_alpha", "isg_get_totallkh", "isg_get_amax", "isg_set_z", "isg_set_freq", "isg_set_qq",
     "isg_set_generation", "isg_set_self_rates", "isg_set_alpha", "isg_keyed_layout", "isg_profile_enable",
     "isg_profile_count", "isg_profile_get", "isg_profile_reset", "isg_gelman_rubin", "isg_selftest",
-    "isg_store_begin", "isg_store_step", "isg_store_fetch", "isg_zq_fallbacks", "isg_zq_resolve_stats", "isg_gather_convg",
+    "isg_store_begin", "isg_store_step", "isg_store_fetch", "isg_zq_fallbacks", "isg_zq_resolve_stats", "isg_zq_resolve_plan", "isg_gather_convg",
     "isg_ctx_create_poly", "isg_poly_update_geno", "isg_get_poly_geno", "isg_get_poly_gs", "isg_get_poly_table", "isg_get_poly_freq2",
 ]
 
