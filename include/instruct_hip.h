@@ -167,8 +167,8 @@ int isg_store_fetch(isg_ctx *ctx, double *qq, double *qq2, double *indvlkh, doub
  * budget) it is redone from the same stream position by the single-workgroup kernel: same results, only slower.  This
  * returns how many sweeps of this context took that path (diagnostics; INSTRUCT_ZQ_TEST_ABORT=n forces the n-th one). */
 long isg_zq_fallbacks(isg_ctx *ctx);
-/* Replay-schedule update_ZQ (K <= 8) first RESOLVES the start position of every individual, a block of individuals per
- * launch on the whole chip, then runs the sweep as one parallel pass (instruct_amd/csrc/isg_resolve_hip.inc;
+/* Replay-schedule update_ZQ (K <= 8) first RESOLVES the start position of every individual, a block of individuals at a
+ * time on the whole chip (all blocks in one launch, or one launch per block), then runs the sweep as one parallel pass (instruct_amd/csrc/isg_resolve_hip.inc;
  * INSTRUCT_ZQ_RESOLVE=0 selects the chain kernels).  Diagnostics of the last sweep:
  * out = {blocks, blocks ended early by a window miss, kernel launches, individuals per block, units per block, 1000 mu,
  * 1000 sigma, draws redone exactly (diagnostic builds)} */

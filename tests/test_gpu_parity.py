@@ -252,6 +252,26 @@ def test_replay_zq_kernel_variants_bit_exact_vs_canonical_oracle(case, env, monk
     h.close()
 
 
+@pytest.mark.parametrize("persist", ["1", "0"])
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 6, 7, 8])
+def test_replay_block_resolver_every_K_bit_exact(K, persist, monkeypatch):
+    """The block kernels take K as a template constant (K = 1 shares K = 2's instance): every K the resolver handles, with all
+    blocks in one launch and with one launch per block; three iterations against the canonical oracle, and the sweeps really
+    went through the resolver."""
+    monkeypatch.setenv("INSTRUCT_ZQ_RESOLVE_PERSIST", persist)
+    geno, an, mi = synth.code_diploid(synth.raw_alleles(150, 1300, max(K, 2), 2, 3, 0.04, 77 + K))
+    h, o, initd = _pair(geno, an, mi, K, capi.SCHED_REPLAY)
+    h.chain_init(initd)
+    o.chain_init(initd)
+    for it in range(3):
+        h.iteration()
+        o.iteration()
+        _same(h, o, ["z", "qq", "qqnum", "generation", "alpha", "self_rates", "freq", "indvlkh", "totallkh", "seeds"], it)
+    st = h.zq_resolve_stats()
+    assert h.zq_fallbacks() == 0 and st["blocks"] >= 1 and (st["launches"] == 1) == (persist == "1")
+    h.close()
+
+
 @pytest.mark.parametrize("case", [(24, 700, 5, 0.05, 2), (8, 33000, 9, 0.0, 3)])
 def test_replay_zq_aborted_cooperative_sweep_is_redone_bit_exact(case, monkeypatch):
     """INSTRUCT_ZQ_TEST_ABORT=2: the second cooperative update_ZQ sweep (= the first iteration's; the first is chain_init's)
