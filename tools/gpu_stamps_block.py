@@ -55,5 +55,3 @@ lp = (u[:, 4] - u[:, 3])
 print("loop cycles of block 50 by XCD (blockIdx % 8):", [int(np.median(lp[x::8])) for x in range(8)])
 idx = np.arange(len(lp)) // 8
 print("loop cycles by position in the XCD's share (eighths):", [int(np.median(lp[(idx * 8 // (idx.max() + 1)) == k])) for k in range(8)])
-st0 = u[:, 1] - u[:, 1].min()
-print("granules-in time skew across units: median %d p95 %d max %d" % (np.median(st0), np.percentile(st0, 95), st0.max()))
