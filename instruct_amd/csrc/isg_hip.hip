@@ -33,6 +33,7 @@
 #include <string.h>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -143,6 +144,9 @@ struct isg_ctx {
 	unsigned long long *d_pipe = nullptr; /* its granules (one line per publishing wave) */
 	unsigned long long *d_spop = nullptr; /* k_spop_tree: limbs of the 2^K exact sums */
 	bool counted = false;                 /* in g_live_ctx */
+	double host_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* INSTRUCT_HOST_TIMING=1: seconds in the stages of replay update_P's host side */
+	long host_n = 0;
+	bool host_timing = false;
 	std::vector<void *> pinned;           /* host vectors registered with the runtime (pin_host): the per-sweep copies of update_P */
 	hipEvent_t ev_cnt = nullptr;          /* replay update_P: the counts have arrived (the tape is still on its way) */
 	double *htape = nullptr;              /* replay update_P: the host loop's uniforms (host_tape_begin); pinned: a 2 MB copy per sweep */
@@ -2919,6 +2923,7 @@ static void pin_host(isg_ctx *c, void *ptr, size_t bytes)
 }
 /* replay update_P: marks / waits for the point of the stream where the counts' copy ends, so that the host can form the shapes and
  * their constants while the uniform tape is generated and copied */
+#define HOST_T(c, k, t0) do { if ((c)->host_timing) { const auto t1_ = std::chrono::steady_clock::now(); (c)->host_t[k] += std::chrono::duration<double>(t1_ - (t0)).count(); (t0) = t1_; } } while (0)
 static int counts_mark(isg_ctx *c)
 {
 	if (!c->ev_cnt) HIPCHK(hipEventCreateWithFlags(&c->ev_cnt, hipEventDisableTiming));
@@ -3014,6 +3019,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	isg_ctx *c = new isg_ctx(); /* value-initialised: every pointer starts null */
 	c->cfg = *cfg;
 	ctx_count(c, +1);
+	{ const char *e_ = getenv("INSTRUCT_HOST_TIMING"); c->host_timing = e_ && atoi(e_) == 1; }
 	memset(&c->d, 0, sizeof(c->d));
 	CtxGuard guard(c); /* any early return below releases what has been allocated so far */
 	const int N = cfg->N, L = cfg->L, K = cfg->K;
@@ -3172,6 +3178,9 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 {
 	if (!c) return;
 	ctx_count(c, -1);
+	if (c->host_timing && c->host_n > 0)
+		fprintf(stderr, "replay update_P host side, ms per sweep over %ld sweeps: counts %.3f  shapes %.3f  constants %.3f  tape %.3f  draws %.3f  upload %.3f\n", c->host_n,
+			1e3 * c->host_t[0] / c->host_n, 1e3 * c->host_t[1] / c->host_n, 1e3 * c->host_t[2] / c->host_n, 1e3 * c->host_t[3] / c->host_n, 1e3 * c->host_t[4] / c->host_n, 1e3 * c->host_t[5] / c->host_n);
 	(void)hipSetDevice(c->cfg.device);
 	(void)hipStreamSynchronize(c->stream);
 	if (c->htape) (void)hipHostFree(c->htape);
@@ -3370,11 +3379,13 @@ extern "C" int isg_update_P(isg_ctx *c)
 	 * (random.c:167-250), so they are drawn sequentially on the host from the counts */
 	HIPCHK(hipMemcpyAsync(c->cnt_h.data(), d.cnt, sizeof(int) * c->cnt_h.size(), hipMemcpyDeviceToHost, c->stream));
 	if (counts_mark(c)) return 1;
+	auto ht0 = std::chrono::steady_clock::now();
 	isg_cursor cur;
 	uint64_t ngamma = 0;
 	for (int j = 0; j < L; j++) ngamma += (c->allelenum[j] > 1) ? (uint64_t)c->allelenum[j] * K : 0;
 	if (host_tape_begin(c, ngamma, &cur)) return 1;
 	if (counts_wait(c)) return 1;
+	HOST_T(c, 0, ht0); /* launches + wait for the counts */
 	/* the shapes (count + 1.0, rdirich's `add`) of all gammas in stream order and their constants, then the draws */
 	c->pshape.resize(ngamma);
 	c->pcoef.resize(ngamma);
@@ -3387,8 +3398,11 @@ extern "C" int isg_update_P(isg_ctx *c)
 				for (int a = 0; a < Aj; a++) c->pshape[g++] = (double)c->cnt_h[((size_t)j * A + a) * K + k] + 1.0;
 			}
 	}
+	HOST_T(c, 1, ht0); /* shapes */
 	host_gamma_coefs(c->pshape.data(), (size_t)ngamma, (HostGammaCoef *)c->pcoef.data());
+	HOST_T(c, 2, ht0); /* constants */
 	HIPCHK(hipStreamSynchronize(c->stream)); /* the tape */
+	HOST_T(c, 3, ht0); /* wait for the tape */
 	host_tape_attach(c, &cur);
 	{
 		size_t g = 0;
@@ -3402,7 +3416,11 @@ extern "C" int isg_update_P(isg_ctx *c)
 			}
 	}
 	host_tape_end(c, &cur);
-	return upload_freq(c);
+	HOST_T(c, 4, ht0); /* the sequential draws */
+	const int rc_up = upload_freq(c);
+	HOST_T(c, 5, ht0); /* transposition + upload launch */
+	c->host_n++;
+	return rc_up;
 }
 
 /* ---- update_S_POP ---- */
