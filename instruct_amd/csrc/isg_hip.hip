@@ -148,6 +148,10 @@ struct isg_ctx {
 	long host_n = 0;
 	bool host_timing = false;
 	std::vector<void *> pinned;           /* host vectors registered with the runtime (pin_host): the per-sweep copies of update_P */
+	hipEvent_t ev_tape = nullptr;         /* ... the tape has arrived (update_P_ahead) */
+	bool ahead_valid = false;             /* counts and tape of the NEXT update_P were requested at the end of update_alpha ... */
+	isg_wh ahead_rng;                     /* ... for this stream position (Z unchanged since: every writer of Z clears the flag) */
+	uint64_t ahead_ngamma = 0;
 	hipEvent_t ev_cnt = nullptr;          /* replay update_P: the counts have arrived (the tape is still on its way) */
 	double *htape = nullptr;              /* replay update_P: the host loop's uniforms (host_tape_begin); pinned: a 2 MB copy per sweep */
 	uint64_t htape_cap = 0;
@@ -3187,6 +3191,8 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	c->htape = nullptr;
 	if (c->ev_cnt) (void)hipEventDestroy(c->ev_cnt);
 	c->ev_cnt = nullptr;
+	if (c->ev_tape) (void)hipEventDestroy(c->ev_tape);
+	c->ev_tape = nullptr;
 	for (void *q : c->pinned) (void)hipHostUnregister(q);
 	c->pinned.clear();
 	store_free(c);
@@ -3359,6 +3365,30 @@ extern "C" int isg_count_alleles(isg_ctx *c, int32_t *counts)
 	return 0;
 }
 
+/* End of update_alpha (replay schedule): the stream position of the next update_P is known and Z is final, while the likelihood
+ * sweep of cal_lkh is still to run on the device.  The next update_P's counts and uniform tape are requested NOW, ahead of cal_lkh
+ * in the stream, so that its host loop runs while cal_lkh does (0.3 ms at config 3) instead of waiting for it.  update_P uses them
+ * only if it starts at exactly this position and nothing has written Z in between. */
+static int update_P_ahead(isg_ctx *c)
+{
+	c->ahead_valid = false;
+	if (c->poly || is_keyed(c) || !c->host_tape) return 0;
+	const int L = c->cfg.L, K = c->cfg.K;
+	if (launch_count(c)) return 1;
+	HIPCHK(hipMemcpyAsync(c->cnt_h.data(), c->d.cnt, sizeof(int) * c->cnt_h.size(), hipMemcpyDeviceToHost, c->stream));
+	if (counts_mark(c)) return 1;
+	uint64_t ngamma = 0;
+	for (int j = 0; j < L; j++) ngamma += (c->allelenum[j] > 1) ? (uint64_t)c->allelenum[j] * K : 0;
+	isg_cursor cur;
+	if (host_tape_begin(c, ngamma, &cur)) return 1;
+	if (!c->ev_tape) HIPCHK(hipEventCreateWithFlags(&c->ev_tape, hipEventDisableTiming));
+	HIPCHK(hipEventRecord(c->ev_tape, c->stream));
+	c->ahead_rng = c->rng;
+	c->ahead_ngamma = ngamma;
+	c->ahead_valid = true;
+	return 0;
+}
+
 /* ---- update_P ---- */
 extern "C" int isg_update_P(isg_ctx *c)
 {
@@ -3366,7 +3396,10 @@ extern "C" int isg_update_P(isg_ctx *c)
 	if (c->poly) return poly_update_P(c);
 	DevView &d = c->d;
 	const int L = c->cfg.L, K = c->cfg.K, A = c->Amax;
-	if (launch_count(c)) return 1;
+	/* requested at the end of the previous iteration's update_alpha (update_P_ahead), for exactly this stream position? */
+	const bool ahead = c->ahead_valid && !is_keyed(c) && c->ahead_rng.s1 == c->rng.s1 && c->ahead_rng.s2 == c->rng.s2 && c->ahead_rng.s3 == c->rng.s3;
+	c->ahead_valid = false;
+	if (!ahead && launch_count(c)) return 1;
 	if (is_keyed(c)) {
 		int n = K * L, B = 256;
 		prof_begin(c);
@@ -3377,13 +3410,20 @@ extern "C" int isg_update_P(isg_ctx *c)
 	}
 	/* replay: the K*L Dirichlets consume the stream in (k, j) order with data-dependent length
 	 * (random.c:167-250), so they are drawn sequentially on the host from the counts */
-	HIPCHK(hipMemcpyAsync(c->cnt_h.data(), d.cnt, sizeof(int) * c->cnt_h.size(), hipMemcpyDeviceToHost, c->stream));
-	if (counts_mark(c)) return 1;
 	auto ht0 = std::chrono::steady_clock::now();
 	isg_cursor cur;
 	uint64_t ngamma = 0;
-	for (int j = 0; j < L; j++) ngamma += (c->allelenum[j] > 1) ? (uint64_t)c->allelenum[j] * K : 0;
-	if (host_tape_begin(c, ngamma, &cur)) return 1;
+	if (ahead) {
+		ngamma = c->ahead_ngamma;
+		cur.s = c->rng;
+		cur.used = 0;
+		cur.tape = nullptr;
+	} else {
+		HIPCHK(hipMemcpyAsync(c->cnt_h.data(), d.cnt, sizeof(int) * c->cnt_h.size(), hipMemcpyDeviceToHost, c->stream));
+		if (counts_mark(c)) return 1;
+		for (int j = 0; j < L; j++) ngamma += (c->allelenum[j] > 1) ? (uint64_t)c->allelenum[j] * K : 0;
+		if (host_tape_begin(c, ngamma, &cur)) return 1;
+	}
 	if (counts_wait(c)) return 1;
 	HOST_T(c, 0, ht0); /* launches + wait for the counts */
 	/* the shapes (count + 1.0, rdirich's `add`) of all gammas in stream order and their constants, then the draws */
@@ -3401,7 +3441,8 @@ extern "C" int isg_update_P(isg_ctx *c)
 	HOST_T(c, 1, ht0); /* shapes */
 	host_gamma_coefs(c->pshape.data(), (size_t)ngamma, (HostGammaCoef *)c->pcoef.data());
 	HOST_T(c, 2, ht0); /* constants */
-	HIPCHK(hipStreamSynchronize(c->stream)); /* the tape */
+	if (ahead) HIPCHK(hipEventSynchronize(c->ev_tape)); /* (not the stream: the previous iteration's cal_lkh may still be running) */
+	else HIPCHK(hipStreamSynchronize(c->stream)); /* the tape */
 	HOST_T(c, 3, ht0); /* wait for the tape */
 	host_tape_attach(c, &cur);
 	{
@@ -3513,6 +3554,7 @@ static void launch_zq(isg_ctx *c, bool chain, isg_wh base, uint64_t pos0, uint64
 }
 extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 {
+	c->ahead_valid = false; /* Z changes: counts requested ahead are stale */
 	HIPCHK(hipSetDevice(c->cfg.device));
 	if (c->poly) return poly_update_ZQ(c, init_flag);
 	const int K = c->cfg.K;
@@ -3678,7 +3720,7 @@ extern "C" int isg_update_alpha(isg_ctx *c)
 		double thr = (1 > mh) ? mh : 1;
 		c->alpha = (host_next(c) < thr) ? ralpha : c->alpha;
 	}
-	return 0;
+	return update_P_ahead(c);
 }
 
 /* ---- cal_lkh ---- */
@@ -3707,6 +3749,7 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 
 extern "C" int isg_update_Z(isg_ctx *c, int init_flag) /* mode 0: update_Z, mcmc.c:1094-1120 (zz[i] is returned by isg_get_generation) */
 {
+	c->ahead_valid = false; /* Z changes: counts requested ahead are stale */
 	if (c->poly || c->cfg.mode != 0) return fail("isg_update_Z: mode 0 (-v 0) only");
 	HIPCHK(hipSetDevice(c->cfg.device));
 	return noadm_update_Z(c, init_flag);
@@ -3759,6 +3802,7 @@ extern "C" int isg_run(isg_ctx *c, long n)
 /* ---- chain init (mcmc.c:471-487, 193-206) ---- */
 extern "C" int isg_chain_init(isg_ctx *c, const float *initd)
 {
+	c->ahead_valid = false; /* Z changes: counts requested ahead are stale */
 	HIPCHK(hipSetDevice(c->cfg.device));
 	if (c->poly) return poly_chain_init(c, initd);
 	const int N = c->cfg.N, K = c->cfg.K;
@@ -3855,6 +3899,7 @@ extern "C" int isg_get_z(isg_ctx *c, int32_t *z)
 }
 extern "C" int isg_set_z(isg_ctx *c, const int32_t *z)
 {
+	c->ahead_valid = false; /* Z changes: counts requested ahead are stale */
 	NOT_POLY(c, "isg_set_z");
 	HIPCHK(hipSetDevice(c->cfg.device));
 	const int N = c->cfg.N, L = c->cfg.L, Lp = c->d.Lp;
