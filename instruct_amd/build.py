@@ -41,7 +41,7 @@ def build_hip(force=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "instruct_hip.h")]
     if force or _newer(LIB_HIP, srcs):
         _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-              "-Wall", "-Wno-unused-function", "-pthread", "-o", LIB_HIP, os.path.join(CSRC, "isg_hip.hip")])
+              "-Wall", "-Wno-unused-function", "-pthread", "-Rpass-analysis=kernel-resource-usage", "-o", LIB_HIP, os.path.join(CSRC, "isg_hip.hip")])
     return LIB_HIP
 
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "isg_get_alpha", "isg_get_totallkh", "isg_get_amax", "isg_set_z", "isg_set_freq", "isg_set_qq",
     "isg_set_generation", "isg_set_self_rates", "isg_set_alpha", "isg_keyed_layout", "isg_profile_enable",
     "isg_profile_count", "isg_profile_get", "isg_profile_reset", "isg_gelman_rubin", "isg_selftest",
-    "isg_store_begin", "isg_store_step", "isg_store_fetch", "isg_zq_fallbacks", "isg_zq_resolve_stats", "isg_zq_resolve_plan", "isg_gather_convg",
+    "isg_store_begin", "isg_store_step", "isg_store_fetch", "isg_zq_fallbacks", "isg_p_device_stats", "isg_zq_spec_stats", "isg_zq_resolve_stats", "isg_zq_resolve_plan", "isg_gather_convg",
     "isg_ctx_create_poly", "isg_poly_update_geno", "isg_get_poly_geno", "isg_get_poly_gs", "isg_get_poly_table", "isg_get_poly_freq2",
 ]
 
@@ -235,6 +235,18 @@ class HipChain:
     def zq_fallbacks(self):
         """replay update_ZQ sweeps that were redone by the single-workgroup kernel (see include/instruct_hip.h)"""
         return self.lib.isg_zq_fallbacks(self.h)
+
+    def zq_spec_stats(self):
+        """replay update_ZQ by shape intervals (isg_spec_hip.inc): sweeps tried / settled / lost, probes and fail bits of the last one"""
+        out = (C.c_long * 8)()
+        self._chk(self.lib.isg_zq_spec_stats(self.h, out))
+        return dict(zip(("tried", "settled", "lost", "probes", "fail_bits", "rounds", "sigma_x1000", "segments"), out))
+
+    def p_device_stats(self):
+        """replay update_P on the device (walk engine): sweeps done there / by the host loop, plan size, window statistics"""
+        out = (C.c_long * 8)()
+        self._chk(self.lib.isg_p_device_stats(self.h, out))
+        return dict(zip(("device_sweeps", "host_sweeps", "segments", "blocks", "table_bytes", "sigma_x1000", "scale_x1000", "kwin_x1000"), out))
 
     def gather_convg(self, rank, world, id_path, mine):
         """ncclAllGather of this chain's log-likelihood samples (RCCL on device buffers) -> [world * n]"""

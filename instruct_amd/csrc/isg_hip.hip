@@ -99,9 +99,13 @@ struct ProfPending {
 struct PolyCtx;
 struct InbreedCtx;
 struct ResolveCtx;
+struct PDevCtx;
+struct SpecCtx;
 struct isg_ctx {
 	isg_config cfg;
 	ResolveCtx *rs = nullptr; /* replay update_ZQ: start positions resolved block-wise (isg_resolve_hip.inc) */
+	SpecCtx *zspec = nullptr; /* replay update_ZQ: start positions resolved from intervals of shapes (isg_spec_hip.inc) */
+	PDevCtx *pdev = nullptr;  /* replay update_P on the device: the Dirichlets' start positions resolved by the walk engine (isg_walk_hip.inc) */
 	PolyCtx *poly = nullptr; /* ploidy 4 state (isg_poly_hip.inc) */
 	InbreedCtx *inb = nullptr; /* mode 4 state (isg_modes_hip.inc) */
 	DevView d;
@@ -772,7 +776,7 @@ struct ZqShared {
  * to 1 (odd consumption, random.c:243-244) or walks that leave the table fall back to the plain loop.
  * Returns (for every thread) the number of uniforms consumed.
  */
-template <int BLOCK, int KMAX>
+template <int BLOCK, int KMAX, bool WRITE = true>
 __device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &sh, int i, isg_wh dstart, double alpha, int par)
 {
 	const double *dtape = nullptr; /* (the cooperative kernels read their uniforms from the tape: dirichlet_coop) */
@@ -855,7 +859,7 @@ __device__ __forceinline__ unsigned dirichlet_block(const DevView &d, ZqShared &
 	const unsigned used = (unsigned)sh.used_total;
 	/* the next individual only needs `used`; qq[i] = g / sum is finished off the critical path
 	 * by lanes of the last wave: hist is double buffered and gval is only rewritten three barriers later */
-	if (t >= BLOCK - 64 && t - (BLOCK - 64) < K) {
+	if (WRITE && t >= BLOCK - 64 && t - (BLOCK - 64) < K) {
 		const int mm = t - (BLOCK - 64);
 		double sum = 0;
 		for (int k2 = 0; k2 < K; k2++) sum += sh.gval[k2];
@@ -950,7 +954,8 @@ __device__ __forceinline__ int bucket_f32(float xf, const float (&F)[KMAX], cons
 
 /* Z draws of one individual; `cur` = stream state at its first position, `off` = that position counted
  * from the start of the phase (index into the uniform tape).  Returns uniforms consumed. */
-template <int BLOCK, int KMAX, bool CHAIN>
+/* WRITE = false: only the consumption is wanted (Z, qq, qqnum stay as they are) */
+template <int BLOCK, int KMAX, bool CHAIN, bool WRITE = true>
 __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i, isg_wh cur, unsigned long long off, int init_flag,
 					   double alpha, isg_wh mult0, isg_wh mult_pass, ZqPrefetch<KMAX> &pf)
 {
@@ -1134,7 +1139,7 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 				if (m < K) wcnt[m] += (int)wave_sum_u32((unsigned)(((m < 4 ? pc0 : pc1) >> (16 * (m & 3))) & 0xffffu));
 			pc0 = pc1 = 0;
 		}
-		if (j0 < d.Lp) {
+		if (WRITE && j0 < d.Lp) {
 			uint2 zo;
 			zo.x = (unsigned)zb;
 			zo.y = (unsigned)(zb >> 32);
@@ -1158,7 +1163,7 @@ __device__ __forceinline__ unsigned zq_one(const DevView &d, ZqShared &sh, int i
 	lds_barrier();
 	STAMP(i, 3);
 	const isg_wh dstart = isg_wh_jump32(&sh.tab, cur, 2u * (unsigned)nvalid);
-	return 2u * (unsigned)nvalid + dirichlet_block<BLOCK, KMAX>(d, sh, i, dstart, alpha, par);
+	return 2u * (unsigned)nvalid + dirichlet_block<BLOCK, KMAX, WRITE>(d, sh, i, dstart, alpha, par);
 }
 
 template <int BLOCK, int KMAX, bool CHAIN>
@@ -2973,6 +2978,8 @@ static bool fits_resident(Kern kern, int threads, long blocks, int device)
 static std::atomic<int> g_live_ctx[64];
 static void ctx_count(isg_ctx *c, int delta);
 #include "isg_resolve_hip.inc"
+#include "isg_walk_hip.inc"
+#include "isg_spec_hip.inc"
 static void ctx_count(isg_ctx *c, int delta)
 {
 	if (c->cfg.device < 0 || c->cfg.device >= 64) return;
@@ -3086,6 +3093,8 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	c->nvalid_total = 0;
 	for (int i = 0; i < N; i++) c->nvalid_total += (uint64_t)nvalid[i];
 	if (resolve_alloc(c, nvalid)) return 1;
+	if (cfg->rng_sched == ISG_SCHED_REPLAY && pdev_create(c, &c->pdev, L, K, Amax, allelenum, 1)) return 1;
+	if (cfg->rng_sched == ISG_SCHED_REPLAY && cfg->mode != 0 && spec_create(c, &c->zspec, nvalid, 2)) return 1;
 	{
 		const int nwv = (Lp + 63) / 64 + 1;
 		std::vector<unsigned> rw((size_t)N * nwv, 0);
@@ -3197,6 +3206,10 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	c->pinned.clear();
 	store_free(c);
 	resolve_free(c);
+	pdev_free(c->pdev);
+	c->pdev = nullptr;
+	spec_free(c->zspec);
+	c->zspec = nullptr;
 	if (c->poly) {
 		poly_ctx_destroy(c);
 		prof_collect(c);
@@ -3373,6 +3386,7 @@ static int update_P_ahead(isg_ctx *c)
 {
 	c->ahead_valid = false;
 	if (c->poly || is_keyed(c) || !c->host_tape) return 0;
+	if (c->pdev && c->pdev->usable) return 0; /* update_P runs on the device: nothing for the host to get ahead with */
 	const int L = c->cfg.L, K = c->cfg.K;
 	if (launch_count(c)) return 1;
 	HIPCHK(hipMemcpyAsync(c->cnt_h.data(), c->d.cnt, sizeof(int) * c->cnt_h.size(), hipMemcpyDeviceToHost, c->stream));
@@ -3408,8 +3422,14 @@ extern "C" int isg_update_P(isg_ctx *c)
 		HIPCHK(hipGetLastError());
 		return refresh_freqf(c);
 	}
-	/* replay: the K*L Dirichlets consume the stream in (k, j) order with data-dependent length
-	 * (random.c:167-250), so they are drawn sequentially on the host from the counts */
+	/* replay: the K*L Dirichlets consume the stream in (k, j) order with data-dependent length (random.c:167-250).  Their start
+	 * positions are resolved on the device (isg_walk_hip.inc) and all of them drawn at once; if that cannot be done (a window
+	 * missed, more alleles at a locus than the engine's groups hold) they are drawn sequentially on the host from the counts */
+	if (!ahead && c->pdev && c->pdev->usable) {
+		bool done = false;
+		if (pdev_update_P(c, c->pdev, &done)) return 1;
+		if (done) return refresh_freqf(c);
+	}
 	auto ht0 = std::chrono::steady_clock::now();
 	isg_cursor cur;
 	uint64_t ngamma = 0;
@@ -3564,6 +3584,11 @@ extern "C" int isg_update_ZQ(isg_ctx *c, int init_flag)
 	uint64_t stride = c->ky[KY_SZ];
 	c->d.tape = nullptr;
 	c->d.tape_len = 0;
+	if (chain && !init_flag && c->zspec) { /* the start positions resolved from intervals of shapes, then one parallel sweep (isg_spec_hip.inc) */
+		bool done = false;
+		if (spec_update_ZQ(c, c->zspec, base, &done)) return 1;
+		if (done) return 0;
+	}
 	if (chain && !init_flag && c->rs) { /* the start positions resolved block-wise, then one parallel sweep (isg_resolve_hip.inc) */
 		bool done = false;
 		if (resolve_update_ZQ(c, base, &done)) return 1;
@@ -4174,6 +4199,35 @@ extern "C" int isg_store_fetch(isg_ctx *c, double *qq, double *qq2, double *indv
 }
 
 extern "C" long isg_zq_fallbacks(isg_ctx *c) { return c->zq_fallbacks; }
+extern "C" int isg_zq_spec_stats(isg_ctx *c, long out[8])
+{
+	for (int k = 0; k < 8; k++) out[k] = 0;
+	if (!c->zspec) return 0;
+	out[0] = c->zspec->sweeps;
+	out[1] = c->zspec->done;
+	out[2] = c->zspec->lost;
+	out[3] = (long)c->zspec->last_probes;
+	out[4] = (long)c->zspec->last_fail;
+	out[5] = (long)c->zspec->last_rounds;
+	out[6] = (long)(1000.0 * c->zspec->walk.sigma);
+	out[7] = (long)c->zspec->walk.plan.seg.size();
+	return 0;
+}
+extern "C" int isg_p_device_stats(isg_ctx *c, long out[8])
+{
+	for (int k = 0; k < 8; k++) out[k] = 0;
+	if (!c->pdev) return 0;
+	const WalkRun &w = c->pdev->walk;
+	out[0] = c->pdev->sweeps - c->pdev->fallbacks;
+	out[1] = c->pdev->fallbacks;
+	out[2] = (long)w.plan.seg.size();
+	out[3] = (long)w.plan.blk.size();
+	out[4] = (long)w.plan.table_bytes;
+	out[5] = (long)(1000.0 * w.sigma);
+	out[6] = (long)(1000.0 * w.scale);
+	out[7] = (long)(1000.0 * w.kwin);
+	return 0;
+}
 extern "C" int isg_profile_enable(isg_ctx *c, int on) { c->prof = on != 0; return 0; }
 extern "C" int isg_profile_count(isg_ctx *c) { prof_collect(c); return (int)c->prof_entries.size(); }
 extern "C" int isg_profile_get(isg_ctx *c, int idx, char *name, int cap, double *ms, long *n)

@@ -28,6 +28,7 @@ EXTRA = {
     "x_a4k3": (25, 1500, 3, 4, 0.20, 2, 1, 1, 0, 1, 1, (25, 11, 2003)),
     "x_wide": (3, 66500, 3, 3, 0.05, 2, 1, 1, 1, 1, 1, (26, 12, 2004)),   # more loci than 128 workgroups x 512 lanes: several passes
     "x_a10k3": (60, 12, 3, 10, 0.05, 2, 1, 1, 1, 1, 1, (27, 13, 2005)),   # microsatellite-like: 10 alleles, 715 genotypes per locus
+    "x_spec": (120, 2500, 4, 4, 0.05, 3, 1, 1, 1, 1, 1, (28, 14, 2006)),    # clusters of ~2400 draws: the interval resolver settles update_ZQ itself
 }
 
 
@@ -354,3 +355,20 @@ def test_config5_full_size_properties(config5_data, sched):
         sig.append((orc.fnv_i32(ch.z()), orc.fnv_i32(ch.geno()), orc.fnv_f64(ch.qq()), ch.totallkh(), ch.seeds()))
         ch.close()
     assert sig[0] == sig[1]
+
+
+def test_tetraploid_interval_resolver_and_device_update_P_take_the_sweeps():
+    """the generated case x_spec (pinned to the oracle line by line above): update_ZQ settled by the interval resolver (isg_spec_hip.inc),
+    update_P_auto's Dirichlets resolved on the device (isg_walk_hip.inc) -- not by their fallbacks"""
+    from instruct_amd import capi, synth
+    N, L, K, A, miss = EXTRA["x_spec"][:5]
+    obs, alleleid, allelenum = synth.code_tetraploid(extra_data("x_spec"))
+    ch = capi.HipPolyChain(obs, alleleid, allelenum, K)
+    ch.setseeds(28, 14, 2006)
+    ch.chain_init(np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32))
+    for _ in range(4):
+        ch.iteration()
+    zs, pd = ch.zq_spec_stats(), ch.p_device_stats()
+    ch.close()
+    assert zs["settled"] >= 3 and zs["lost"] == 0, zs
+    assert pd["device_sweeps"] == 4 and pd["host_sweeps"] == 0, pd
