@@ -76,10 +76,14 @@ def timed_steps(chain, steps, warmup, world):
 # sweep at the resolved positions.  Its roofline entry is the phase: 2 N L P bytes / phase time.
 ZQ_RESOLVE = ("k_tapef", "k_zq_blocks", "k_zq_at")
 ZQ_RESOLVE_PER_BLOCK = ("k_tapef", "k_zq_block", "k_zq_at")
+# round 3: the start positions from intervals of the Dirichlets' shapes (isg_spec_hip.inc): expected counts, accept-bit tables, walks,
+# probes on the trajectory, then the same sweep kernel
+ZQ_SPEC = ("k_zexpect", "k_wk_centers_Z", "k_wk_table_Z", "k_wk_walk_Z", "k_zs_band", "k_zq_probe", "k_zs_offs", "k_zq_at")
 
 
 def roofline(prof, kernel, bytes_per_launch, traffic):
     if isinstance(kernel, tuple):
+        kernel = tuple(k for k in kernel if k in prof)
         ms = sum(prof[k][0] for k in kernel)
         n = prof[kernel[-1]][1]
         name = "update_ZQ phase: " + " + ".join(kernel)
@@ -194,7 +198,7 @@ def tetra_leg(device, steps, warmup, with_cpu):
         ch.profile(False)
         prof = ch.profile_results()
         ch.close()
-        zq = next(k for k in ("k4_zq_coop", "k4_zq_keyed", "k4_zq") if k in prof)
+        zq = next(k for k in ("k_zq_at", "k4_zq_coop", "k4_zq_keyed", "k4_zq") if k in prof)  # (k_zq_at: the sweep at resolved positions, k4_zq's code)
         # update_ZQ launch, algorithmic bytes: genotype + Z byte per allele copy, in both schedules (the replay schedule's
         # uniform tape is traffic, not algorithm)
         alg = 2 * 4 * nvalid
@@ -297,6 +301,8 @@ def main():
         dt, lk, prof = timed_steps(ch, args.steps, args.warmup, world)
         if sched != capi.SCHED_REPLAY:
             zq = "k_zq_keyed"
+        elif "k_zexpect" in prof:
+            zq = ZQ_SPEC + tuple(k for k in ("k_tapef", "k_zq_blocks", "k_zq_block") if k in prof)  # (+ whatever sweeps fell through to the block resolver)
         elif "k_zq_blocks" in prof:
             zq = ZQ_RESOLVE
         elif "k_zq_block" in prof:
@@ -307,6 +313,8 @@ def main():
         rl = roofline(prof, zq, 2 * N * L * P, traffic.get("update_ZQ_replay" if isinstance(zq, tuple) else zq))
         if isinstance(zq, tuple):
             rl["resolve"] = ch.zq_resolve_stats()
+            rl["interval_resolver"] = ch.zq_spec_stats()
+            rl["update_P_device"] = ch.p_device_stats()
             rl["fallback_sweeps"] = ch.zq_fallbacks()
         ckrep = min(len(lk), 20)
         gr = None

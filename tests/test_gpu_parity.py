@@ -224,13 +224,15 @@ def test_edge_shapes_bit_exact_vs_canonical_oracle(case, sched):
 
 # replay update_ZQ kernel variants: the default picks k_zq_pipe (K <= 8, one locus per lane, Lp < 32768), k_zq_spec or
 # k_zq_coop; the environment switches force the other ones; all of them must give the oracle's state
-_R0 = {"INSTRUCT_ZQ_RESOLVE": "0"}   # the chain kernels (the default resolves the start positions block-wise first)
-_P0 = {"INSTRUCT_ZQ_RESOLVE_PERSIST": "0"}   # one launch per block instead of k_zq_blocks (all blocks in one launch)
-@pytest.mark.parametrize("env", [{}, {"INSTRUCT_ZQ_RESOLVE_UNITS": "16"}, {"INSTRUCT_ZQ_RESOLVE_A": "0.6"}, {"INSTRUCT_ZQ_RESOLVE_A": "12"},
+_S0 = {"INSTRUCT_ZQ_SPEC_RESOLVE": "0"}   # without the interval resolver (isg_spec_hip.inc), which is tried first by default: the block resolver
+_R0 = dict(_S0, INSTRUCT_ZQ_RESOLVE="0")   # ... and without that: the chain kernels
+_P0 = dict(_S0, INSTRUCT_ZQ_RESOLVE_PERSIST="0")   # one launch per block instead of k_zq_blocks (all blocks in one launch)
+@pytest.mark.parametrize("env", [{}, _S0, dict(_S0, INSTRUCT_ZQ_RESOLVE_UNITS="16"), dict(_S0, INSTRUCT_ZQ_RESOLVE_A="0.6"), dict(_S0, INSTRUCT_ZQ_RESOLVE_A="12"),
                                  _P0, dict(_P0, INSTRUCT_ZQ_RESOLVE_UNITS="16"), dict(_P0, INSTRUCT_ZQ_RESOLVE_A="0.6"), dict(_P0, INSTRUCT_ZQ_RESOLVE_A="12"),
                                  _R0, dict(_R0, INSTRUCT_ZQ_PIPE="0"),
                                  dict(_R0, INSTRUCT_ZQ_PIPE_XCD="0"), dict(_R0, INSTRUCT_ZQ_SPEC="0"), dict(_R0, INSTRUCT_ZQ_XCD="1"),
-                                 dict(_R0, INSTRUCT_ZQ_SPEC="0", INSTRUCT_ZQ_XCD="1"), dict(_R0, INSTRUCT_ZQ_COOP="0")])
+                                 dict(_R0, INSTRUCT_ZQ_SPEC="0", INSTRUCT_ZQ_XCD="1"), dict(_R0, INSTRUCT_ZQ_COOP="0"),
+                                 {"INSTRUCT_P_DEVICE": "0"}])
 @pytest.mark.parametrize("case", [(24, 700, 5, 0.05, 2), (6, 40000, 3, 0.02, 2), (8, 33000, 9, 0.0, 3),
                                   (10, 20000, 8, 0.03, 3), (16, 3000, 2, 0.1, 2)])
 def test_replay_zq_kernel_variants_bit_exact_vs_canonical_oracle(case, env, monkeypatch):
@@ -259,6 +261,7 @@ def test_replay_block_resolver_every_K_bit_exact(K, persist, monkeypatch):
     blocks in one launch and with one launch per block; three iterations against the canonical oracle, and the sweeps really
     went through the resolver."""
     monkeypatch.setenv("INSTRUCT_ZQ_RESOLVE_PERSIST", persist)
+    monkeypatch.setenv("INSTRUCT_ZQ_SPEC_RESOLVE", "0")   # (the interval resolver would take these sweeps first)
     geno, an, mi = synth.code_diploid(synth.raw_alleles(150, 1300, max(K, 2), 2, 3, 0.04, 77 + K))
     h, o, initd = _pair(geno, an, mi, K, capi.SCHED_REPLAY)
     h.chain_init(initd)
@@ -280,6 +283,7 @@ def test_replay_zq_aborted_cooperative_sweep_is_redone_bit_exact(case, monkeypat
     the same stream position: state and stream position equal the oracle's, and the chain carries on."""
     N, L, K, miss, nall = case
     monkeypatch.setenv("INSTRUCT_ZQ_TEST_ABORT", "2")
+    monkeypatch.setenv("INSTRUCT_ZQ_SPEC_RESOLVE", "0")   # (the cooperative sweeps are what this test is about)
     geno, an, mi = synth.code_diploid(synth.raw_alleles(N, L, K, 2, nall, miss, 23))
     h, o, initd = _pair(geno, an, mi, K, capi.SCHED_REPLAY)
     h.chain_init(initd)
@@ -330,9 +334,12 @@ def test_long_run_stays_bit_exact(mode, sched):
     h.close()
 
 
-def test_config2_twenty_iterations_bit_exact():
+@pytest.mark.parametrize("spec", ["1", "0"])
+def test_config2_twenty_iterations_bit_exact(spec, monkeypatch):
     """BASELINE config 2 (N=2000, L=1000, K=5, mode 2), replay schedule: Z, allele counts, generations, qq and the
-    stream position after each of 20 iterations against the canonical oracle (SURVEY 8d parity gate)."""
+    stream position after each of 20 iterations against the canonical oracle (SURVEY 8d parity gate); with update_ZQ's start
+    positions resolved from shape intervals (the default) and by the block resolver."""
+    monkeypatch.setenv("INSTRUCT_ZQ_SPEC_RESOLVE", spec)
     geno, an, mi = synth.make_diploid(2000, 1000, 5)
     h, o, initd = _pair(geno, an, mi, 5, capi.SCHED_REPLAY, 2)
     h.chain_init(initd)
@@ -341,16 +348,22 @@ def test_config2_twenty_iterations_bit_exact():
         h.iteration()
         o.iteration()
         _same(h, o, ["z", "count_alleles", "generation", "qq", "self_rates", "alpha", "totallkh", "seeds"], it)
-    # the sweeps really went through the block-wise resolution of the start positions (not its fallback)
-    st = h.zq_resolve_stats()
-    # (launches: 1 = k_zq_blocks, all blocks in one launch; one launch per block when its workgroups cannot all be resident)
-    assert h.zq_fallbacks() == 0 and st["blocks"] >= 2000 // 64 and (st["launches"] == 1 or st["launches"] > st["blocks"]) and 1 <= st["D"] <= 64
+    # the sweeps really went through the resolution of the start positions (not the chain kernels behind it)
+    st, sp, pd = h.zq_resolve_stats(), h.zq_spec_stats(), h.p_device_stats()
+    assert h.zq_fallbacks() == 0 and pd["device_sweeps"] == 20 and pd["host_sweeps"] == 0, pd
+    if spec == "1":
+        assert sp["settled"] >= 18, sp
+    else:
+        # (launches: 1 = k_zq_blocks, all blocks in one launch; one launch per block when its workgroups cannot all be resident)
+        assert sp["tried"] == 0 and st["blocks"] >= 2000 // 64 and (st["launches"] == 1 or st["launches"] > st["blocks"]) and 1 <= st["D"] <= 64
     h.close()
 
 
-def test_config3_two_iterations_bit_exact(full_size):
+@pytest.mark.parametrize("spec", ["1", "0"])
+def test_config3_two_iterations_bit_exact(full_size, spec, monkeypatch):
     """BASELINE config 3 (N=10000, L=5000, K=5), replay schedule, against the canonical oracle at full size
     (the oracle needs ~10 s per iteration here, hence two)."""
+    monkeypatch.setenv("INSTRUCT_ZQ_SPEC_RESOLVE", spec)
     geno, an, mi = full_size
     h, o, initd = _pair(geno, an, mi, 5, capi.SCHED_REPLAY, 2)
     h.chain_init(initd)
@@ -359,7 +372,8 @@ def test_config3_two_iterations_bit_exact(full_size):
         h.iteration()
         o.iteration()
         _same(h, o, ["z", "count_alleles", "generation", "qq", "self_rates", "alpha", "totallkh", "seeds"], it)
-    assert h.zq_fallbacks() == 0 and h.zq_resolve_stats()["blocks"] > 100
+    assert h.zq_fallbacks() == 0 and (h.zq_spec_stats()["settled"] == 2 if spec == "1" else h.zq_resolve_stats()["blocks"] > 100)
+    assert h.p_device_stats()["device_sweeps"] == 2
     h.close()
 
 

@@ -130,6 +130,7 @@ def test_tetraploid_block_resolved_update_zq_gives_the_same_lines(name, monkeypa
         raw = synth.raw_alleles(cfg[0], cfg[1], cfg[2], 4, cfg[3], cfg[4], 20260401 + sorted(ALLO_EXTRA).index(name)) if allo else extra_data(name)
     want = hip_lines(name, cfg, raw, allo=allo)
     monkeypatch.setenv("INSTRUCT_ZQ_RESOLVE_P4", "1")
+    monkeypatch.setenv("INSTRUCT_ZQ_SPEC_RESOLVE", "0")   # (the interval resolver would be tried first)
     assert hip_lines(name, cfg, raw, allo=allo) == want
 
 
@@ -137,6 +138,7 @@ def test_tetraploid_single_workgroup_zq_kernel_gives_the_same_lines(monkeypatch)
     """INSTRUCT_ZQ_COOP=0 selects the one-workgroup update_ZQ kernel (no uniform tape, no hand-offs)"""
     coop = hip_lines("t1")
     monkeypatch.setenv("INSTRUCT_ZQ_COOP", "0")
+    monkeypatch.setenv("INSTRUCT_ZQ_SPEC_RESOLVE", "0")
     assert hip_lines("t1") == coop
 
 
@@ -145,6 +147,7 @@ def test_tetraploid_aborted_cooperative_sweep_is_redone_bit_exact(monkeypatch):
     restored and the single-workgroup kernel redoes the sweep -- every later dump line unchanged"""
     want = hip_lines("t1")
     monkeypatch.setenv("INSTRUCT_ZQ_TEST_ABORT", "2")
+    monkeypatch.setenv("INSTRUCT_ZQ_SPEC_RESOLVE", "0")
     assert hip_lines("t1") == want
 
 
