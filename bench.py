@@ -10,9 +10,12 @@ N=10000 individuals x L=5000 loci, K=5, diploid, mode 2 (-v 2 -e 1 -y 1), synthe
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, one chain per GPU)
 
 `value` is measured on the REPLAY schedule (stream positions identical to the reference: Z, allele
-counts, generations and seeds are bit-identical to the reference run with the same seeds).  The same
-JSON line carries the KEYED schedule (counter-based positions, all consumers concurrent) under "keyed".
-Rank 0 at N=1 also times the reference's own CPU sweeps on the host cores ("cpu_baseline").
+counts, generations and seeds are bit-identical to the reference run with the same seeds), over EXACTLY
+K steps with the per-kernel profiling OFF; a second, profiled pass of the same chain gives `kernels_ms`
+and the roofline entries (HIP events on the launch stream).  The same JSON line carries the KEYED
+schedule (counter-based positions, all consumers concurrent) under "keyed" and BASELINE config 5
+(ploidy 4) under "ploidy4".  Rank 0 at N=1 also times the reference's own CPU sweeps on the host
+cores ("cpu_baseline").
 """
 from __future__ import annotations
 
@@ -36,6 +39,7 @@ WORKLOADS = {
     "c2": dict(N=2000, L=1000, K=5, name="config2: N=2000 L=1000 K=5 diploid mode 2, 1 chain per GPU"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILED_STEPS = 20    # the second pass: per-kernel times
 
 
 def sync():
@@ -44,11 +48,10 @@ def sync():
 
 
 def timed_steps(chain, steps, warmup, world):
+    """(seconds for exactly `steps` iterations, profiling off; log-likelihood samples; per-kernel profile of a second pass)"""
     import torch.distributed as dist
     chain.run(warmup)
-    lk = []
-    chain.profile_reset()
-    chain.profile(True)
+    chain.profile(False)
     if world > 1:
         dist.barrier()
     sync()
@@ -59,10 +62,15 @@ def timed_steps(chain, steps, warmup, world):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    chain.profile(False)
-    prof = chain.profile_results()
     if world > 1:
         dt = multichain.max_over_ranks(dt)
+    # second pass, same chain, per-kernel HIP events on (not part of `value`)
+    chain.profile_reset()
+    chain.profile(True)
+    chain.run(PROFILED_STEPS)
+    chain.totallkh()
+    chain.profile(False)
+    prof = chain.profile_results()
     # log-likelihood samples for the Gelman-Rubin exchange: a few more (untimed) stored iterations
     lk = [last]
     for _ in range(5):
@@ -71,30 +79,60 @@ def timed_steps(chain, steps, warmup, world):
     return dt, lk, prof
 
 
-# the replay schedule's update_ZQ is a PHASE of kernels: the uniforms as floats, the resolution of the start positions block by block
-# (k_zq_blocks: one launch, all blocks; k_zq_block: one launch per block when the workgroups cannot all be resident), then the
-# sweep at the resolved positions.  Its roofline entry is the phase: 2 N L P bytes / phase time.
-ZQ_RESOLVE = ("k_tapef", "k_zq_blocks", "k_zq_at")
-ZQ_RESOLVE_PER_BLOCK = ("k_tapef", "k_zq_block", "k_zq_at")
-# round 3: the start positions from intervals of the Dirichlets' shapes (isg_spec_hip.inc): expected counts, accept-bit tables, walks,
-# probes on the trajectory, then the same sweep kernel
-ZQ_SPEC = ("k_zexpect", "k_wk_centers_Z", "k_wk_table_Z", "k_wk_walk_Z", "k_zs_band", "k_zq_probe", "k_zs_offs", "k_zq_at")
+# update_ZQ in the replay schedule is a PHASE of kernels.  Round 3 (isg_spec_hip.inc): expected cluster counts, accept-bit tables and walks
+# that resolve every individual's start position, probes on the trajectory, then the sweep at the resolved positions (k_zq_at).  The block
+# resolver of round 2 (k_tapef + k_zq_blocks / k_zq_block + k_zq_at) takes the sweeps the interval resolver hands on.
+ZQ_PHASE = ("k_zexpect", "k_wk_centers_Z", "k_wk_table_Z", "k_wk_walk_Z", "k_zs_band", "k_zq_probe", "k_zs_offs", "k_zq_at", "k_tapef", "k_zq_blocks", "k_zq_block",
+            "k_tape", "k_zq_pipe", "k_zq_spec", "k_zq_coop", "k_zq_chain", "k4_zq_coop", "k4_zq", "k_zq_keyed", "k4_zq_keyed")
 
 
-def roofline(prof, kernel, bytes_per_launch, traffic):
-    if isinstance(kernel, tuple):
-        kernel = tuple(k for k in kernel if k in prof)
-        ms = sum(prof[k][0] for k in kernel)
-        n = prof[kernel[-1]][1]
-        name = "update_ZQ phase: " + " + ".join(kernel)
-    else:
-        ms, n = prof[kernel]
-        name = kernel
+def kernel_alg_bytes(name, N, L, P, nvalid_copies, extra):
+    """ALGORITHMIC bytes of one launch of a kernel: what it must read and write, not what it happens to move."""
+    cells = nvalid_copies if nvalid_copies else N * L * P
+    table = {
+        # sweeps over the genotype / Z bytes
+        "k_zq_at": 2 * cells, "k_zq_keyed": 2 * cells, "k4_zq_keyed": 2 * cells, "k4_zq": 2 * cells, "k4_zq_coop": 2 * cells,
+        "k_zq_blocks": 2 * cells, "k_zq_pipe": 2 * cells, "k_zq_chain": 2 * cells,
+        "k_zexpect": cells,                                   # the genotype byte of every copy
+        "k_count": 2 * cells, "k_loglik_pair": 2 * cells, "k_loglik_lkh": 2 * cells,
+        "k4_geno": 3 * cells + cells, "k4_lkd": 3 * cells, "k4_sweep_counts": 2 * cells,
+        # the accept-bit tables: one byte written per (group, window column); inputs are a few bytes per gamma
+        "k_wk_table_Z": extra.get("table_bytes_Z", 0), "k_wk_table_P": extra.get("table_bytes_P", 0),
+    }
+    return table.get(name)
+
+
+def roofline_of(prof, steps, N, L, P, nvalid_copies, extra, traffic, phase_bytes):
+    """the dominant kernel of the profiled pass (largest total time) against the HBM roofline, and the update_ZQ phase as a sub-entry"""
+    tot = {k: ms for k, (ms, n) in prof.items()}
+    dom = max(tot, key=tot.get)
+    ms, n = prof[dom]
+    alg = kernel_alg_bytes(dom, N, L, P, nvalid_copies, extra)
     avg_s = ms / n * 1e-3
-    gbs = bytes_per_launch / avg_s / 1e9
-    return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 6), "avg_launch_ms": round(ms / n, 4), "alg_bytes_per_launch": bytes_per_launch,
-            "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)"}
+    out = {"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(ms / n, 4), "launches_per_step": round(n / steps, 2),
+           "ms_per_step": round(ms / steps, 4), "alg_bytes_per_launch": alg,
+           "traffic": traffic.get(dom), "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)"}
+    if alg:
+        gbs = alg / avg_s / 1e9
+        out.update(achieved=round(gbs, 3), frac=round(gbs / HBM_PEAK_GBS, 6))
+    else:
+        out.update(achieved=None, frac=None)
+    if dom.startswith("k_wk_table"):
+        out["note"] = ("accept-bit tables of the walk engine: VALU work (one rgamma attempt decision per (gamma, window column)), hardly any HBM traffic -- "
+                       "its algorithmic bytes are the table bytes it writes; the streaming sweep is `sweep_kernel`, the whole phase `phase`")
+    ph = [k for k in ZQ_PHASE if k in prof]
+    ph_ms = sum(prof[k][0] for k in ph) / steps
+    out["phase"] = {"name": "update_ZQ: " + " + ".join(ph), "ms_per_step": round(ph_ms, 4), "alg_bytes": phase_bytes,
+                    "achieved": round(phase_bytes / (ph_ms * 1e-3) / 1e9, 3), "frac": round(phase_bytes / (ph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                    "traffic": traffic.get("update_ZQ_replay")}
+    sk = next((k for k in ("k_zq_at", "k_zq_keyed", "k4_zq_keyed", "k4_zq_coop", "k4_zq") if k in prof), None)
+    if sk:
+        sms, sn = prof[sk]
+        sb = kernel_alg_bytes(sk, N, L, P, nvalid_copies, extra)
+        out["sweep_kernel"] = {"kernel": sk, "avg_launch_ms": round(sms / sn, 4), "alg_bytes_per_launch": sb,
+                               "achieved": round(sb / (sms / sn * 1e-3) / 1e9, 3), "frac": round(sb / (sms / sn * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                               "traffic": traffic.get(sk)}
+    return out
 
 
 def load_traffic():
@@ -140,9 +178,34 @@ def cpu_baseline(geno, K, seeds):
     return {"value": round(1.0 / dt, 6), "unit": "iterations/s", "cores": 1, "kind": "port", "sample": sample, "s_per_iter": dt}
 
 
-def concurrent_chains_leg(geno, an, mi, K, device, steps):
-    """Independent replay chains sharing ONE GPU (one host thread + one HIP stream per chain, seeds per chain as for
-    the multi-GPU runs): the replay update_ZQ kernel is latency bound on 20 of the 256 CUs, so chains overlap."""
+def chain_worker(workload, rank, steps, device, rendezvous):
+    """a worker PROCESS of the several-chains-on-one-GPU leg: its own context on `device`, waits for the go file, runs `steps` iterations"""
+    w = WORKLOADS[workload]
+    geno, an, mi = synth.make_diploid(w["N"], w["L"], w["K"])
+    h = capi.HipChain(geno, an, mi, w["K"], rng_sched=capi.SCHED_REPLAY, device=device)
+    h.setseeds(*multichain.rank_seeds((13, 4, 1972), rank))
+    h.chain_init(np.array([h.ran1() for _ in range(w["K"])], dtype=np.float32))
+    h.run(2)
+    h.totallkh()
+    open(os.path.join(rendezvous, "ready.%d" % rank), "w").close()
+    go = os.path.join(rendezvous, "go")
+    t_wait = time.time()
+    while not os.path.exists(go):
+        if time.time() - t_wait > 600:
+            raise SystemExit("worker %d: no go file" % rank)
+        time.sleep(0.002)
+    t0 = time.perf_counter()
+    h.run(steps)
+    h.totallkh()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"rank": rank, "s": dt, "start": t0, "end": t0 + dt}), flush=True)
+    h.close()
+
+
+def concurrent_chains_leg(geno, an, mi, K, device, steps, workload):
+    """Independent replay chains sharing ONE GPU, seeds per chain as for the multi-GPU runs: (a) one host thread + one HIP stream per chain in
+    this process, (b) one PROCESS per chain (what the multi-GPU launcher starts when chains outnumber GPUs; each with its own HIP context and
+    its own host threads) -- the only evidence about host-side contention obtainable on a one-GPU box."""
     import threading
     res = {}
     chains = []
@@ -167,18 +230,38 @@ def concurrent_chains_leg(geno, an, mi, K, device, steps):
         res[str(n)] = {"chain_iterations_per_s": round(n * steps / dt, 3), "ms_per_step_per_chain": round(dt / steps * 1e3, 3)}
     for h in chains:
         h.close()
-    res["note"] = "aggregate over n chains on one GPU, replay schedule; not part of `value` (1 chain per GPU)"
+    res["note"] = "aggregate over n chains on one GPU (threads of this process), replay schedule; not part of `value` (1 chain per GPU)"
+    # (b) processes: 4 workers (the test boxes allow at most 6 processes on a GPU at once, this one included)
+    nproc = 4
+    with tempfile.TemporaryDirectory() as rv:
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--chain-worker", str(r), "--steps", str(steps), "--workload", workload,
+                                   "--device", str(device), "--rendezvous", rv], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for r in range(nproc)]
+        t_wait = time.time()
+        while sum(os.path.exists(os.path.join(rv, "ready.%d" % r)) for r in range(nproc)) < nproc and time.time() - t_wait < 600:
+            if any(p.poll() is not None for p in procs):
+                break
+            time.sleep(0.01)
+        open(os.path.join(rv, "go"), "w").close()
+        outs = []
+        for p in procs:
+            o, _ = p.communicate(timeout=900)
+            try:
+                outs.append(json.loads(o.decode().strip().splitlines()[-1]))
+            except Exception:
+                outs = None
+                break
+    if outs:
+        span = max(o["s"] for o in outs)
+        res["processes"] = {"n": nproc, "chain_iterations_per_s": round(nproc * steps / span, 3), "ms_per_step_per_chain": round(span / steps * 1e3, 3),
+                            "note": "one process per chain on one GPU (own HIP context, own host threads), aggregate over the slowest worker's time"}
     return res
 
 
 def tetra_leg(device, steps, warmup, with_cpu):
-    """BASELINE.json config 5 on one GPU: N=10000 L=20000 K=10 ploidy 4 (autotetraploid), 5 % missing, replay
-    schedule.  The synthetic population is 1000 distinct individuals x 10 replicas (the generator's numpy
-    coder takes minutes at 8e8 allele copies); every replica is sampled independently by the chain."""
-    N, L, K, A, base = 10000, 20000, 10, 4, 1000
-    raw = synth.raw_alleles(base, L, K, 4, A, 0.05, 20260105)
-    obs, alleleid, allelenum = synth.code_tetraploid_fast(raw)
-    obs, alleleid = np.tile(obs, (N // base, 1, 1)), np.tile(alleleid, (N // base, 1))
+    """BASELINE.json config 5 on one GPU: N=10000 L=20000 K=10 ploidy 4 (autotetraploid), 5 % missing, replay schedule; 10000 DISTINCT
+    synthetic individuals (instruct_amd/host/synth_fast.c: the numpy generator's arrays, built in seconds)."""
+    N, L, K, A = 10000, 20000, 10, 4
+    obs, alleleid, allelenum = synth.make_tetraploid_fast(N, L, K, A, 0.05, 20260105)
     nvalid = int((alleleid > 0).sum())
     traffic = load_traffic()
 
@@ -187,28 +270,33 @@ def tetra_leg(device, steps, warmup, with_cpu):
         ch.setseeds(13, 4, 1972)
         ch.chain_init(np.array([np.float32(ch.ran1()) for _ in range(K)], dtype=np.float32))
         ch.run(warmup)
-        ch.profile_reset()
-        ch.profile(True)
+        ch.profile(False)
         sync()
         t0 = time.perf_counter()
         ch.run(nsteps)
         last = ch.totallkh()
         sync()
         dt = time.perf_counter() - t0
+        psteps = max(2, nsteps // 2)
+        ch.profile_reset()
+        ch.profile(True)
+        ch.run(psteps)
+        ch.totallkh()
         ch.profile(False)
         prof = ch.profile_results()
+        extra = {"table_bytes_Z": ch.zq_spec_stats().get("table_bytes", 0), "table_bytes_P": ch.p_device_stats()["table_bytes"]}
+        stats = {"interval_resolver": ch.zq_spec_stats(), "update_P_device": ch.p_device_stats(), "fallback_sweeps": ch.zq_fallbacks()} if sched == capi.SCHED_REPLAY else {}
         ch.close()
-        zq = next(k for k in ("k_zq_at", "k4_zq_coop", "k4_zq_keyed", "k4_zq") if k in prof)  # (k_zq_at: the sweep at resolved positions, k4_zq's code)
-        # update_ZQ launch, algorithmic bytes: genotype + Z byte per allele copy, in both schedules (the replay schedule's
-        # uniform tape is traffic, not algorithm)
-        alg = 2 * 4 * nvalid
-        return {"value": round(nsteps / dt, 4), "unit": "iterations/s", "ms_per_step": round(dt / nsteps * 1e3, 3),
-                "roofline": roofline(prof, zq, alg, traffic.get(zq)),
-                "kernels_ms": {k: round(ms / n, 4) for k, (ms, n) in sorted(prof.items())},
-                "iteration_frac_of_hbm": round(5 * N * L * 4 / (dt / nsteps) / 1e9 / HBM_PEAK_GBS, 6), "last_totallkh": last}
-    res = {"workload": "config5: N=10000 L=20000 K=10 ploidy 4 (-p 4 -ap 1), 5% missing, 1 chain; value = replay schedule"}
+        out = {"value": round(nsteps / dt, 4), "unit": "iterations/s", "ms_per_step": round(dt / nsteps * 1e3, 3),
+               "roofline": roofline_of(prof, psteps, N, L, 4, 4 * nvalid, extra, traffic, 2 * 4 * nvalid),
+               "kernels_ms": {k: round(ms / n, 4) for k, (ms, n) in sorted(prof.items())},
+               "kernels_ms_per_step": {k: round(ms / psteps, 4) for k, (ms, n) in sorted(prof.items())},
+               "iteration_frac_of_hbm": round(5 * N * L * 4 / (dt / nsteps) / 1e9 / HBM_PEAK_GBS, 6), "last_totallkh": last}
+        out.update(stats)
+        return out
+    res = {"workload": "config5: N=10000 L=20000 K=10 ploidy 4 (-p 4 -ap 1), 5% missing, 10000 distinct individuals, 1 chain; value = replay schedule"}
     res.update(one(capi.SCHED_REPLAY, steps))
-    res["keyed"] = one(capi.SCHED_KEYED, 4 * steps)
+    res["keyed"] = one(capi.SCHED_KEYED, steps)
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench_poly")
     if with_cpu and os.path.exists(exe):
         # the reference's own ploidy-4 sweeps (poly_geno.c:98-116, bare loop: nothing but the sweeps between the clock reads)
@@ -235,36 +323,22 @@ def tetra_leg(device, steps, warmup, with_cpu):
     return res
 
 
-def measured_copy_gbs(dev):
-    """HBM bandwidth of a plain device-to-device copy on this GPU (1 GiB, read + written bytes), torch's stream"""
-    import torch
-    n = 1 << 30
-    x = torch.empty(n, dtype=torch.uint8, device=f"cuda:{dev}")
-    y = torch.empty_like(x)
-    x.zero_()
-    for _ in range(2):
-        y.copy_(x)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    reps = 8
-    for _ in range(reps):
-        y.copy_(x)
-    e1.record()
-    torch.cuda.synchronize()
-    return round(2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-keyed", action="store_true")
     ap.add_argument("--no-tetra", action="store_true", help="skip the ploidy 4 (config 5) leg")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the several-chains-on-one-GPU leg (profiling: keeps per-kernel averages single-chain)")
+    ap.add_argument("--chain-worker", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--rendezvous", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.chain_worker is not None:
+        return chain_worker(args.workload, args.chain_worker, args.steps, args.device, args.rendezvous)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -299,22 +373,12 @@ def main():
         ch.setseeds(*seeds)
         ch.chain_init(np.array([ch.ran1() for _ in range(K)], dtype=np.float32))
         dt, lk, prof = timed_steps(ch, args.steps, args.warmup, world)
-        if sched != capi.SCHED_REPLAY:
-            zq = "k_zq_keyed"
-        elif "k_zexpect" in prof:
-            zq = ZQ_SPEC + tuple(k for k in ("k_tapef", "k_zq_blocks", "k_zq_block") if k in prof)  # (+ whatever sweeps fell through to the block resolver)
-        elif "k_zq_blocks" in prof:
-            zq = ZQ_RESOLVE
-        elif "k_zq_block" in prof:
-            zq = ZQ_RESOLVE_PER_BLOCK
-        else:
-            zq = next(k for k in ("k_zq_pipe", "k_zq_spec", "k_zq_coop", "k_zq_chain") if k in prof)
-        # update_ZQ: reads the genotype byte and writes the Z byte of every allele copy
-        rl = roofline(prof, zq, 2 * N * L * P, traffic.get("update_ZQ_replay" if isinstance(zq, tuple) else zq))
-        if isinstance(zq, tuple):
-            rl["resolve"] = ch.zq_resolve_stats()
+        extra = {"table_bytes_Z": ch.zq_spec_stats().get("table_bytes", 0), "table_bytes_P": ch.p_device_stats()["table_bytes"]}
+        rl = roofline_of(prof, PROFILED_STEPS, N, L, P, 0, extra, traffic, 2 * N * L * P)
+        if sched == capi.SCHED_REPLAY:
             rl["interval_resolver"] = ch.zq_spec_stats()
             rl["update_P_device"] = ch.p_device_stats()
+            rl["block_resolver"] = ch.zq_resolve_stats()
             rl["fallback_sweeps"] = ch.zq_fallbacks()
         ckrep = min(len(lk), 20)
         gr = None
@@ -322,6 +386,7 @@ def main():
             gr = multichain.gelman_rubin_all_ranks(np.array(lk[-ckrep:]))  # RCCL all-gather over xGMI
         out[tag] = dict(value=world * args.steps / dt, ms_per_step=dt / args.steps * 1e3, roofline=rl, gelman_rubin=gr,
                         kernels_ms={k: round(ms / n, 4) for k, (ms, n) in sorted(prof.items())},
+                        kernels_ms_per_step={k: round(ms / PROFILED_STEPS, 4) for k, (ms, n) in sorted(prof.items())},
                         # whole iteration against the fused-design contract figure 3*N*L*P bytes
                         iteration_frac_of_hbm=round(3 * N * L * P / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
                         last_totallkh=lk[-1])
@@ -332,10 +397,11 @@ def main():
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(geno, K, seeds)
         head = out["replay"]
-        copy_gbs = measured_copy_gbs(local)  # the fraction against a measured device-to-device copy as well
+        copy_gbs = round(capi.copy_bandwidth(local), 1)  # the fraction against a measured device-to-device copy as well (16-byte accesses)
         for o in out.values():
             o["roofline"]["copy_peak_measured"] = copy_gbs
-            o["roofline"]["frac_of_measured_copy"] = round(o["roofline"]["achieved"] / copy_gbs, 6)
+            if o["roofline"].get("achieved"):
+                o["roofline"]["frac_of_measured_copy"] = round(o["roofline"]["achieved"] / copy_gbs, 6)
         line = {
             "metric": "MCMC iterations/sec (update_P+update_ZQ+update_SG) at NxLxK", "value": round(head["value"], 4),
             "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -345,8 +411,9 @@ def main():
                        "chains": world, "parallelism": f"{world} independent chain(s), one per GPU"},
             "roofline": head["roofline"], "cpu_baseline": cpu,
             "speedup_vs_cpu": (round(head["value"] / world / cpu["value"], 2) if cpu else None),
-            "kernels_ms": head["kernels_ms"], "iteration_frac_of_hbm": head["iteration_frac_of_hbm"],
+            "kernels_ms": head["kernels_ms"], "kernels_ms_per_step": head["kernels_ms_per_step"], "iteration_frac_of_hbm": head["iteration_frac_of_hbm"],
             "gelman_rubin": head["gelman_rubin"],
+            "timing": f"value: exactly {args.steps} iterations after {args.warmup} warm-up, per-kernel events off; kernels_ms / roofline: a second pass of {PROFILED_STEPS} iterations with events on",
         }
         if "keyed" in out:
             k = out["keyed"]
@@ -357,8 +424,8 @@ def main():
                              "note": "counter-based stream positions: bit-identical to the oracle's keyed schedule, statistically equivalent to the reference"}
         if world == 1 and not args.no_tetra:
             if not args.no_concurrent:
-                line["concurrent_chains"] = concurrent_chains_leg(geno, an, mi, K, local, max(4, args.steps // 2))
-            line["ploidy4"] = tetra_leg(local, max(2, args.steps // 4), 1, not args.no_cpu)
+                line["concurrent_chains"] = concurrent_chains_leg(geno, an, mi, K, local, max(10, args.steps // 4), args.workload)
+            line["ploidy4"] = tetra_leg(local, max(4, args.steps // 10), 2, not args.no_cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

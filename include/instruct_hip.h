@@ -186,7 +186,7 @@ int isg_zq_resolve_plan(int units, double mu, double sigma, double a, double sha
  * one parallel pass with every Dirichlet's consumption checked.  A sweep this path cannot settle (many small clusters: every
  * candidate uncertain) goes to the block resolver / chain kernels above; INSTRUCT_ZQ_SPEC_RESOLVE=0 disables it.  Diagnostics:
  * out = {sweeps tried, settled, lost (handed on), probes of the last sweep, fail bits of the last sweep (1 window missed, 2 irregular
- * byte, 16 probe list full, 32 consumption check, 64 rounds did not settle), probe rounds of the last sweep, 1000 sigma, segments} */
+ * byte, 16 probe list full, 32 consumption check, 64 rounds did not settle), probe rounds of the last sweep, bytes of the accept-bit tables, segments} */
 int isg_zq_spec_stats(isg_ctx *ctx, long out[8]);
 /* Replay-schedule update_P on the device (instruct_amd/csrc/isg_walk_hip.inc): the start position of every Dirichlet of
  * mcmc.c:846-857 / poly_geno.c:426-434 is resolved by the walk engine (accept bits of every (gamma, stream position) on the
@@ -202,6 +202,10 @@ int isg_profile_enable(isg_ctx *ctx, int on);
 int isg_profile_count(isg_ctx *ctx);
 int isg_profile_get(isg_ctx *ctx, int idx, char *name, int name_cap, double *total_ms, long *launches);
 int isg_profile_reset(isg_ctx *ctx);
+
+/* measured device-to-device copy bandwidth (read + written GB/s) of `bytes` bytes with 16-byte loads and stores, `reps` timed
+ * repetitions: the ceiling a streaming kernel has on this GPU, reported by bench.py beside the 8 TB/s specification */
+int isg_copy_bandwidth(int device, size_t bytes, int reps, double *gbs);
 
 /* host-only exhaustive check of the device's integer/float shortcuts (LCG step without division,
  * quotient by reciprocal + fma, table skip-ahead) against the plain formulas of random.c:19-47 */

@@ -59,6 +59,10 @@ def build_host(force=False):
     robj = os.path.join(HOST, "data_interface_stream.o")
     if force or _newer(robj, [rsrc, os.path.join(HOST, "instruct_types.h")]):
         _run(["gcc", "-O2", "-fPIC", "-Wall", "-c", rsrc, "-o", robj])
+    # the benchmark's synthetic tetraploid generator (instruct_amd/synth.py uses it when it is there)
+    ssrc, slib = os.path.join(HOST, "synth_fast.c"), os.path.join(PKG, "libisg_synth.so")
+    if force or _newer(slib, [ssrc]):
+        _run(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-Wall", ssrc, "-o", slib])
     # the multi-GPU launcher (plain C, no GPU call of its own)
     msrc, mexe = os.path.join(HOST, "instruct_mgpu.c"), os.path.join(HOST, "instruct_mgpu")
     if force or _newer(mexe, [msrc]):

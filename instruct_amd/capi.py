@@ -24,7 +24,7 @@ EXPORTS = [
     "isg_get_alpha", "isg_get_totallkh", "isg_get_amax", "isg_set_z", "isg_set_freq", "isg_set_qq",
     "isg_set_generation", "isg_set_self_rates", "isg_set_alpha", "isg_keyed_layout", "isg_profile_enable",
     "isg_profile_count", "isg_profile_get", "isg_profile_reset", "isg_gelman_rubin", "isg_selftest",
-    "isg_store_begin", "isg_store_step", "isg_store_fetch", "isg_zq_fallbacks", "isg_p_device_stats", "isg_zq_spec_stats", "isg_zq_resolve_stats", "isg_zq_resolve_plan", "isg_gather_convg",
+    "isg_store_begin", "isg_store_step", "isg_store_fetch", "isg_zq_fallbacks", "isg_p_device_stats", "isg_zq_spec_stats", "isg_copy_bandwidth", "isg_zq_resolve_stats", "isg_zq_resolve_plan", "isg_gather_convg",
     "isg_ctx_create_poly", "isg_poly_update_geno", "isg_get_poly_geno", "isg_get_poly_gs", "isg_get_poly_table", "isg_get_poly_freq2",
 ]
 
@@ -240,7 +240,7 @@ class HipChain:
         """replay update_ZQ by shape intervals (isg_spec_hip.inc): sweeps tried / settled / lost, probes and fail bits of the last one"""
         out = (C.c_long * 8)()
         self._chk(self.lib.isg_zq_spec_stats(self.h, out))
-        return dict(zip(("tried", "settled", "lost", "probes", "fail_bits", "rounds", "sigma_x1000", "segments"), out))
+        return dict(zip(("tried", "settled", "lost", "probes", "fail_bits", "rounds", "table_bytes", "segments"), out))
 
     def p_device_stats(self):
         """replay update_P on the device (walk engine): sweeps done there / by the host loop, plan size, window statistics"""
@@ -334,6 +334,16 @@ class HipPolyChain(HipChain):
         """the used entries of a table in the reference's order (k, j, g < G_j)"""
         mask = np.arange(self.GS)[None, :] < self.gcount[:, None]
         return np.ascontiguousarray(tab[:, mask])
+
+
+def copy_bandwidth(device=0, nbytes=1 << 30, reps=8):
+    """device-to-device copy bandwidth in GB/s (read + written), 16-byte accesses (isg_copy_bandwidth)"""
+    lib = load()
+    lib.isg_copy_bandwidth.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    g = C.c_double(0)
+    if lib.isg_copy_bandwidth(device, nbytes, reps, C.byref(g)) != 0:
+        raise IsgError(lib.isg_last_error().decode())
+    return g.value
 
 
 def gelman_rubin(vec, numchains, totrep):

@@ -2982,9 +2982,9 @@ static void ctx_count(isg_ctx *c, int delta);
 #include "isg_spec_hip.inc"
 static void ctx_count(isg_ctx *c, int delta)
 {
-	if (c->cfg.device < 0 || c->cfg.device >= 64) return;
-	if (delta > 0 && !c->counted) { g_live_ctx[c->cfg.device].fetch_add(1); c->counted = true; }
-	if (delta < 0 && c->counted) { g_live_ctx[c->cfg.device].fetch_sub(1); c->counted = false; }
+	if (c->cfg.device < 0) return;
+	if (delta > 0 && !c->counted) { g_live_ctx[c->cfg.device & 63].fetch_add(1); c->counted = true; }
+	if (delta < 0 && c->counted) { g_live_ctx[c->cfg.device & 63].fetch_sub(1); c->counted = false; }
 }
 
 /* ploidy 4 (isg_poly_hip.inc, included further down) */
@@ -3085,7 +3085,11 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 			DALLOC(d.lftab, double, (size_t)L * Amax * K);
 			const size_t ent = (size_t)50 * L * Amax * Amax * K;
 			if (cfg->mode == 2 && ent * sizeof(double) <= ((size_t)1 << 30)) { DALLOC(d.lltab, double, ent); } /* (mode 3: unclamped initial generations) */
-			if (cfg->mode == 4 && (ent / 50) * sizeof(double) <= ((size_t)1 << 30)) { DALLOC(d.lltab, double, ent / 50); } /* one slot: log genofreq_inbreedcoff */
+			if (cfg->mode == 4) { /* one slot: log genofreq_inbreedcoff.  Mode 4 has no table-free path: up to half of what the device has free */
+				size_t fr = 0, tot = 0;
+				if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)1 << 31;
+				if ((ent / 50) * sizeof(double) <= fr / 2) { DALLOC(d.lltab, double, ent / 50); }
+			}
 		}
 	}
 	c->d_tape = nullptr;
@@ -3179,7 +3183,7 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	keyed_layout(c);
 	if (cfg->mode == 0 && !d.lftab) return fail("isg_ctx_create: mode 0 needs its log frequency table (INSTRUCT_LL_TABLES must not be 0)");
 	if (cfg->mode == 4) {
-		if (!d.lltab) return fail("isg_ctx_create: mode 4 needs its log-likelihood table (INSTRUCT_LL_TABLES must not be 0; L * Amax^2 * K doubles, at most 1 GiB)");
+		if (!d.lltab) return fail("isg_ctx_create: mode 4 needs its log-likelihood table (INSTRUCT_LL_TABLES must not be 0; L * Amax^2 * K doubles, at most half of the free device memory)");
 		if (inbreed_alloc(c)) return 1;
 	}
 	guard.release();
@@ -3789,6 +3793,8 @@ extern "C" int isg_update_S_IND(isg_ctx *c) /* mode 3: update_S_IND, mcmc.c:864-
 
 extern "C" int isg_iteration(isg_ctx *c)
 {
+	/* keyed positions grow with the iteration count; the device's skip-ahead reduces them through a double (isg_mod_u64: exact below 2^52) */
+	if (is_keyed(c) && iter_base(c) + c->ky[KY_BLK] >= (1ull << 52)) return fail("isg_iteration: the keyed schedule's stream positions reach 2^52 (the generator's period is 6.95e12 anyway)");
 	if (c->poly) {
 		HIPCHK(hipSetDevice(c->cfg.device));
 		return poly_iteration(c);
@@ -4209,7 +4215,7 @@ extern "C" int isg_zq_spec_stats(isg_ctx *c, long out[8])
 	out[3] = (long)c->zspec->last_probes;
 	out[4] = (long)c->zspec->last_fail;
 	out[5] = (long)c->zspec->last_rounds;
-	out[6] = (long)(1000.0 * c->zspec->walk.sigma);
+	out[6] = (long)c->zspec->walk.plan.table_bytes;
 	out[7] = (long)c->zspec->walk.plan.seg.size();
 	return 0;
 }
@@ -4241,6 +4247,41 @@ extern "C" int isg_profile_get(isg_ctx *c, int idx, char *name, int cap, double 
 extern "C" int isg_profile_reset(isg_ctx *c) { prof_collect(c); c->prof_entries.clear(); return 0; }
 
 /* ---- host-side self test of the integer/float shortcuts used on the device (no GPU needed) ---- */
+/* device-to-device copy bandwidth of this GPU with 16-byte loads and stores (the microarchitecture guide's float4 copy): what a
+ * streaming kernel can at best reach here; bench.py reports roofline fractions against it next to the 8 TB/s specification */
+__global__ void __launch_bounds__(256) k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
+{
+	const size_t stride = (size_t)gridDim.x * 256;
+	for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) dst[k] = src[k];
+}
+extern "C" int isg_copy_bandwidth(int device, size_t bytes, int reps, double *gbs)
+{
+	*gbs = 0;
+	HIPCHK(hipSetDevice(device));
+	const size_t n = bytes / 16;
+	uint4 *a = nullptr, *b = nullptr;
+	HIPCHK(hipMalloc((void **)&a, n * 16));
+	if (hipMalloc((void **)&b, n * 16) != hipSuccess) { (void)hipFree(a); return fail("isg_copy_bandwidth: out of device memory"); }
+	HIPCHK(hipMemset(a, 1, n * 16));
+	hipEvent_t e0, e1;
+	HIPCHK(hipEventCreate(&e0));
+	HIPCHK(hipEventCreate(&e1));
+	int cus = 256;
+	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+	const dim3 grid((unsigned)(cus * 8));
+	for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, 0, (const uint4 *)a, b, n);
+	HIPCHK(hipEventRecord(e0, 0));
+	for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, 0, (const uint4 *)a, b, n);
+	HIPCHK(hipEventRecord(e1, 0));
+	HIPCHK(hipEventSynchronize(e1));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+	*gbs = 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9; /* read + written */
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	(void)hipFree(a); (void)hipFree(b);
+	return 0;
+}
+
 extern "C" int isg_selftest(void)
 {
 	static const uint32_t M[3] = {ISG_M1, ISG_M2, ISG_M3}, A[3] = {ISG_A1, ISG_A2, ISG_A3};

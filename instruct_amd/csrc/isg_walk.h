@@ -232,7 +232,7 @@ ISG_HD int wk_try_interval_f32(const WkCoefI k, float u1, float u2, int *unc)
 {
 	const float t = 1.0f - 1.86f * u1, at = t < 0 ? -t : t;
 	const float v = u2 + k.c5 * t;
-	const float dv = k.e5 * at + 3e-7f;
+	const float dv = k.e5 * at + 2e-6f; /* (+ the uniforms' single precision images: 1e-6 each) */
 	if (!(v > 0.f)) { *unc = !(v + dv < 0.f); return 0; } /* (NaN: uncertain) */
 	if (!(v < 1.0f)) { *unc = !(v - dv > 1.0f); return 0; }
 	const float vm = v - dv;
@@ -379,9 +379,13 @@ ISG_HD void wk_table_body(const WkTableArgs A, int wg, int nthreads, unsigned ch
 			}
 			for (; i < ntape; i += nthreads) tape[i] = src[i];
 		} else {
-			for (int i0 = t * 8; i0 < ntape; i0 += nthreads * 8) {
+			for (int i0 = t * 16; i0 < ntape; i0 += nthreads * 16) { /* 16 per skip-ahead */
 				isg_wh s = isg_wh_jump(A.tab, A.base, s0 + (unsigned long long)i0);
-				for (int k = 0; k < 8 && i0 + k < ntape; k++) tape[i0 + k] = (float)isg_wh_next(&s);
+				for (int k = 0; k < 16 && i0 + k < ntape; k++) {
+					isg_wh_step(&s);
+					/* interval mode: the bits are speculation anyway, the cheaper single precision evaluation (error < 1e-6) will do */
+					tape[i0 + k] = interval ? isg_wh_value_f32(&s) : (float)isg_wh_value(&s);
+				}
 			}
 		}
 		for (int k = t; k < ng * nw * (interval ? 2 : 1); k += nthreads) rows[k] = 0u;

@@ -26,6 +26,8 @@
 #define _GNU_SOURCE
 #include <errno.h>
 #include <math.h>
+#include <signal.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -178,6 +180,7 @@ int main(int argc, char **argv)
 	{ /* stale files of an earlier run would satisfy the pollers */
 		char p[4200];
 		snprintf(p, sizeof(p), "%s/nccl_id", dir); unlink(p);
+		snprintf(p, sizeof(p), "%s/abort", dir); unlink(p);
 		snprintf(p, sizeof(p), "%s/convg_all.bin", dir); unlink(p);
 		for (r = 0; r < W; r++) { snprintf(p, sizeof(p), "%s/convg.%d.bin", dir, r); unlink(p); }
 	}
@@ -219,15 +222,53 @@ int main(int argc, char **argv)
 		w[r].pid = spawn(exe, av, w[r].log, r % gpus, r, inf_K == 1 ? 0 : W, dir, gather, W > gpus);
 		free(av);
 	}
-	for (r = 0; r < W; r++) {
-		if (waitpid(w[r].pid, &w[r].status, 0) < 0) die("waitpid failed", NULL);
-	}
-	for (r = 0; r < W; r++) {
-		if (!WIFEXITED(w[r].status) || WEXITSTATUS(w[r].status) != 0) {
+	/* ---- wait for them in whatever order they finish.  The first worker that fails ends the run: its siblings may be waiting for it
+	 * (the RCCL rendezvous, ncclCommInitRank, the all-gather) and would wait for ever, so an `abort` file tells the pollers, the rest are
+	 * terminated, and the failing worker's output is shown.  Nothing is restarted: a failed rank is a failed run. ---- */
+	{
+		int left = W, failed = -1;
+		while (left > 0) {
+			int st = 0;
+			const pid_t pid = waitpid(-1, &st, 0);
+			if (pid < 0) {
+				if (errno == EINTR) continue;
+				die("waitpid failed", NULL);
+			}
+			for (r = 0; r < W && w[r].pid != pid; r++) { }
+			if (r == W) continue; /* not one of ours */
+			w[r].status = st;
+			w[r].pid = 0;
+			left--;
+			if (failed < 0 && (!WIFEXITED(st) || WEXITSTATUS(st) != 0)) {
+				char p[4200];
+				FILE *a;
+				time_t t0;
+				failed = r;
+				snprintf(p, sizeof(p), "%s/abort", dir);
+				if ((a = fopen(p, "w")) != NULL) { fprintf(a, "worker %d failed\n", r); fclose(a); }
+				for (j = 0; j < W; j++) if (w[j].pid > 0) kill(w[j].pid, SIGTERM);
+				/* a few seconds for them to go, then no more patience */
+				t0 = time(NULL);
+				while (left > 0) {
+					const pid_t q = waitpid(-1, &st, WNOHANG);
+					if (q > 0) {
+						for (j = 0; j < W && w[j].pid != q; j++) { }
+						if (j < W) { w[j].pid = 0; w[j].status = st; left--; }
+					} else if (q < 0 && errno != EINTR) {
+						break;
+					} else {
+						if (time(NULL) - t0 > 5) { for (j = 0; j < W; j++) if (w[j].pid > 0) kill(w[j].pid, SIGKILL); }
+						usleep(20000);
+					}
+				}
+			}
+		}
+		if (failed >= 0) {
 			size_t n = 0;
-			char *log = slurp(w[r].log, &n);
-			fprintf(stdout, "instruct_mgpu: worker %d failed (status %d); its output follows\n%s\n", r, w[r].status, log ? log + (n > 3000 ? n - 3000 : 0) : "");
-			die("a worker failed; see ", w[r].log);
+			char *log = slurp(w[failed].log, &n);
+			fprintf(stdout, "instruct_mgpu: worker %d failed (status %d), the other workers were stopped; its output follows\n%s\n", failed, w[failed].status,
+				log ? log + (n > 3000 ? n - 3000 : 0) : "");
+			die("a worker failed; see ", w[failed].log);
 		}
 	}
 	/* ---- assemble the result file ---- */

@@ -243,3 +243,36 @@ def make_diploid(N, L, K, missing_frac=0.0, n_alleles=2, seed=20260101):
     if n_alleles == 2:
         return code_biallelic_fast(raw)
     return code_diploid(raw)
+
+
+def _cum_alleles(K, L, n_alleles, seed):
+    """cumulative allele frequencies [K][L][A] exactly as raw_alleles forms them"""
+    kk = np.arange(K * L, dtype=np.uint64)
+    if n_alleles == 2:
+        p = 0.05 + 0.9 * _uniform(seed, 1, kk).reshape(K, L)
+        return np.stack([p, np.ones_like(p)], axis=-1)
+    e = -np.log1p(-_uniform(seed, 1, np.arange(K * L * n_alleles, dtype=np.uint64)))
+    e = e.reshape(K, L, n_alleles)
+    cum = np.cumsum(e / e.sum(-1, keepdims=True), axis=-1)
+    cum[..., -1] = 1.0
+    return cum
+
+
+def make_tetraploid_fast(N, L, K, n_alleles=4, missing_frac=0.05, seed=20260105):
+    """(obs, alleleid, allelenum) of code_tetraploid(raw_alleles(N, L, K, 4, n_alleles, missing_frac, seed)), built by
+    instruct_amd/host/synth_fast.c (libisg_synth.so) in seconds at config 5's size; the numpy path if the library is not there."""
+    import ctypes as C
+    import os
+    lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libisg_synth.so")
+    if not os.path.exists(lib_path):
+        return code_tetraploid_fast(raw_alleles(N, L, K, 4, n_alleles, missing_frac, seed))
+    lib = C.CDLL(lib_path)
+    lib.isg_synth_tetraploid.argtypes = [C.c_long, C.c_long, C.c_int, C.c_int, C.c_double, C.c_uint64] + [C.c_void_p] * 4
+    cum = np.ascontiguousarray(_cum_alleles(K, L, n_alleles, seed), dtype=np.float64)
+    obs = np.empty((N, L, 4), dtype=np.int32)
+    alleleid = np.empty((N, L), dtype=np.int32)
+    allelenum = np.empty(L, dtype=np.int32)
+    rc = lib.isg_synth_tetraploid(N, L, K, n_alleles, missing_frac, seed, cum.ctypes.data, obs.ctypes.data, alleleid.ctypes.data, allelenum.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("isg_synth_tetraploid failed")
+    return obs, alleleid, allelenum

@@ -136,3 +136,14 @@ def test_update_ZQ_by_shape_intervals_with_several_segments_and_a_narrow_band(mo
     st = h.zq_spec_stats()
     assert st["segments"] >= 5 and st["tried"] >= 1, st
     h.close()
+
+
+@pytest.mark.parametrize("K", [9, 10, 12, 16])
+def test_update_ZQ_start_positions_resolved_for_K_beyond_8(K):
+    """K = 9 .. 16 (the block resolver stops at 8): the interval resolver settles the sweeps, nothing goes to the chain kernels"""
+    geno, an, mi = synth.make_diploid(160, 1000 * K, K)
+    h, o = _pair(geno, an, mi, K)
+    _iterate_and_compare(h, o, 3, K)
+    st = h.zq_spec_stats()
+    assert st["settled"] == 3 and st["lost"] == 0 and h.zq_fallbacks() == 0, st
+    h.close()

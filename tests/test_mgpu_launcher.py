@@ -152,3 +152,101 @@ def test_abi_rccl_all_gather_on_device_buffers(tmp_path):
     got = h.gather_convg(0, 1, tmp_path / "id", mine)
     assert np.array_equal(got, mine)
     h.close()
+
+
+def test_launcher_fails_fast_when_a_worker_dies(tmp_path):
+    """A worker that dies (bad flag, HIP error, nrerror) must end the run at once: its siblings may be blocked in the RCCL
+    rendezvous waiting for it.  Rank 1 of four exits with an error after a moment, the others would run for a minute: the
+    launcher reports rank 1's output, leaves the `abort` file for pollers, stops the others, returns non-zero within seconds
+    and leaves no child behind."""
+    import signal
+    import time
+    from instruct_amd import build
+    build.build_host()
+    exe = tmp_path / "worker.sh"
+    pids = tmp_path / "pids"
+    exe.write_text("#!/bin/sh\necho $$ >> %s\nif [ \"$INSTRUCT_MGPU_RANK\" = 1 ]; then sleep 0.3; echo 'ERROR: \nworker one is unwell'; exit 3; fi\nexec sleep 60\n" % pids)
+    os.chmod(str(exe), 0o755)
+    out = tmp_path / "ff.txt"
+    t0 = time.time()
+    log = subprocess.run([MGPU, "--exe", str(exe), "--gpus", "4", "--gather", "rccl", "--keep", "--", "-o", str(out), "-c", "4", "-K", "2"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60)
+    dt = time.time() - t0
+    assert log.returncode != 0 and dt < 10, (log.returncode, dt)
+    assert b"worker 1 failed" in log.stdout and b"worker one is unwell" in log.stdout
+    assert os.path.exists(str(out) + ".mgpu/abort")
+    time.sleep(0.2)
+    for pid in [int(x) for x in open(str(pids)).read().split()]:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, "worker %d still running" % pid
+
+
+@pytest.mark.gpu
+def test_launcher_eight_chains_on_one_gpu_through_files(tmp_path):
+    """More workers than GPUs (`--gpus 1 --gather file`, eight processes sharing the test box's one MI355X): every chain's block equals
+    the separate `-c 1 -s s+r` run of the same program (ranks 0 and 1 also the reference's own, tests/golden/mgpu_rank*), the
+    Gelman-Rubin line is the statistic of the eight chains' exact samples."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "InStruct_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
+    _build()
+    W = 6   # (the test box lets at most 6 processes use the GPU together)
+    out = tmp_path / "eight.txt"
+    cmd = [MGPU, "--exe", exe, "--gpus", "1", "--gather", "file", "--keep", "--", "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out)] + \
+        MG.MGPU_BASE + ["-c", str(W), "-g", "1", "-s"] + [str(s) for s in MG.MGPU_SEEDS]
+    log = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert log.returncode == 0 and b"THE JOB IS SUCCESSFULLY FINISHED" in log.stdout, log.stdout[-3000:]
+    head, blocks = _blocks(str(out))
+    assert len(blocks) == W and ("Chain Number=%d" % W).encode() in head
+    for r in range(2):
+        assert blocks[r] == _blocks(os.path.join(gu.GOLDEN, "mgpu_rank%d_cli_output.txt" % r))[1][0]
+    samples = []
+    for r in range(W):
+        sep = tmp_path / ("sep%d.txt" % r)
+        cf = tmp_path / ("sep%d.cf" % r)
+        one = subprocess.run([exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(sep), "-cf", str(cf)] + MG.mgpu_rank_cli(r), stdout=subprocess.DEVNULL, timeout=600)
+        assert one.returncode == 0
+        assert blocks[r] == _blocks(str(sep))[1][0], r
+        mine = np.fromfile(os.path.join(str(out) + ".mgpu", "convg.%d.bin" % r))
+        assert mine.size == 6 and np.allclose(mine, _cf_values(str(cf)), rtol=0, atol=1e-6)
+        samples.append(mine)
+    gr = orc.gelman_rubin(np.concatenate(samples), W, 6)
+    m = re.search(rb"The Gelman-Rubin statistics for the convergence of log-likelihood is (\S+)\.\n", open(str(out), "rb").read())
+    # (six chains of six samples: repperchain = 6 / 6 = 1 and the reference's formula divides by rep - 1 = 0, check_converg.c:121-141: nan there, nan here)
+    got = float(m.group(1))
+    assert m and ((np.isnan(got) and np.isnan(gr)) or abs(got - gr) <= 1.1e-6 * max(1.0, abs(gr))), (got, gr)
+
+
+@pytest.mark.gpu
+def test_launcher_k_scan_around_the_drop_in(tmp_path):
+    """-ik 1 -kv 2 4 sharded one worker per K around the drop-in (three processes on the one GPU): every section is what a separate
+    run of the same program with that K and the worker's seeds writes, the optimal K the one with the smallest DIC"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "InStruct_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/InStruct_hip not built (needs the reference objects; built in the dev container)")
+    _build()
+    out = tmp_path / "k.txt"
+    cli = [a for a in MG.KSCAN_CLI]
+    k = cli.index("-kv")
+    cli[k + 1:k + 3] = ["2", "4"]
+    log = subprocess.run([MGPU, "--exe", exe, "--gpus", "1", "--", "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(out)] + cli, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert log.returncode == 0, log.stdout[-3000:]
+    data = open(str(out), "rb").read()
+    dic = {}
+    for idx, K in enumerate((2, 3, 4)):
+        assert data.count(b"The current K is %d\n" % K) == 1
+        sep = tmp_path / ("sep%d.txt" % K)
+        one = [a for a in MG.KSCAN_CLI]
+        for flag, n in (("-ik", 1), ("-kv", 2), ("-K", 1), ("-s", 3)):
+            q = one.index(flag)
+            del one[q:q + n + 1]
+        cmd = [exe, "-d", os.path.join(gu.GOLDEN, "c1.txt"), "-o", str(sep)] + one + ["-K", str(K), "-ik", "0", "-s"] + [str(s + idx) for s in (13, 4, 1972)]
+        assert subprocess.run(cmd, stdout=subprocess.DEVNULL, timeout=600).returncode == 0
+        sec = data.split(b"The current K is %d\n" % K)[1].split(b"\n\nThe current K is")[0].split(b"\n\nThe range of value for K")[0]
+        assert sec == b"\n\n\nChain#" + open(str(sep), "rb").read().split(b"\n\n\nChain#", 1)[1], K
+        dic[K] = min(float(x) for x in re.findall(rb"information criterion of this model is (-?[\d.]+)\.\n", sec))
+    assert data.endswith(b"\n\nThe range of value for K is (2 - 4)!\nThe optimal K is %d\n" % min(dic, key=dic.get))

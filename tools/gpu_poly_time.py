@@ -10,13 +10,8 @@ from instruct_amd import capi, synth
 N, L, K, A = (int(x) for x in sys.argv[1:5])
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 sched = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-base = min(N, 1000)
 t = time.time()
-raw = synth.raw_alleles(base, L, K, 4, A, 0.05, 20260105)
-obs, alleleid, allelenum = synth.code_tetraploid_fast(raw)
-if N > base:
-    rep = N // base
-    obs, alleleid = np.tile(obs, (rep, 1, 1)), np.tile(alleleid, (rep, 1))
+obs, alleleid, allelenum = synth.make_tetraploid_fast(N, L, K, A, 0.05, 20260105)   # N distinct individuals (C generator)
 print("data %.1fs" % (time.time() - t), obs.shape, flush=True)
 t = time.time()
 ch = capi.HipPolyChain(obs, alleleid, allelenum, K, rng_sched=sched)
@@ -36,3 +31,4 @@ for it in range(iters):
 for k, (ms, n) in sorted(ch.profile_results().items(), key=lambda kv: -kv[1][0]):
     print("%-16s %10.3f ms total %6d launches %10.3f ms each" % (k, ms, n, ms / n))
 print("resolve", ch.zq_resolve_stats(), "fallbacks", ch.zq_fallbacks())
+print("interval resolver", ch.zq_spec_stats(), "update_P device", ch.p_device_stats())

@@ -19,9 +19,7 @@ for sched in (capi.SCHED_REPLAY, capi.SCHED_KEYED):
     h.close()
 if len(sys.argv) <= 2 or sys.argv[2] != "no-tetra":  # both schedules
     K = 10
-    raw = synth.raw_alleles(1000, 20000, K, 4, 4, 0.05, 20260105)
-    obs, alleleid, allelenum = synth.code_tetraploid_fast(raw)
-    obs, alleleid = np.tile(obs, (10, 1, 1)), np.tile(alleleid, (10, 1))
+    obs, alleleid, allelenum = synth.make_tetraploid_fast(10000, 20000, K, 4, 0.05, 20260105)
     for sched in (capi.SCHED_REPLAY, capi.SCHED_KEYED):
         ch = capi.HipPolyChain(obs, alleleid, allelenum, K, rng_sched=sched)
         ch.setseeds(13, 4, 1972)

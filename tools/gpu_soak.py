@@ -23,5 +23,6 @@ for blk in range(iters // every):
         a, b = getattr(h, name)(), getattr(o, name)()
         ok = np.array_equal(a, np.asarray(b)) if isinstance(a, np.ndarray) else a == b
         assert ok, (blk, name)
-    print("iteration %d identical; fallbacks %d; resolver %s; %.0f s" % ((blk + 1) * every, h.zq_fallbacks(), h.zq_resolve_stats(), time.time() - t0), flush=True)
+    print("iteration %d identical; fallbacks %d; interval resolver %s; update_P %s; block resolver %s; %.0f s" %
+          ((blk + 1) * every, h.zq_fallbacks(), h.zq_spec_stats(), h.p_device_stats(), h.zq_resolve_stats(), time.time() - t0), flush=True)
 print("SOAK OK", iters, "iterations, fallbacks", h.zq_fallbacks())

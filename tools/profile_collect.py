@@ -14,9 +14,11 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "gpurun_out")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
-SHORT = [("k_zq_pipe", "k_zq_pipe"), ("k_zq_spec", "k_zq_spec"), ("k_zq_coop", "k_zq_coop"), ("k4_zq_coop", "k4_zq_coop"), ("k_zq<256", "k_zq_keyed"), ("k_zq<512", "k_zq_chain"),
+SHORT = [("k_wk_table<0>", "k_wk_table_P"), ("k_wk_table<1>", "k_wk_table_Z"), ("k_zq_at", "k_zq_at"), ("k_zq_probe", "k_zq_probe"), ("k4_zq_probe", "k4_zq_probe"),
+         ("k_zexpect", "k_zexpect"), ("k4_zexpect_fin", "k4_zexpect_fin"), ("k4_zexpect", "k4_zexpect"),
+         ("k_zq_pipe", "k_zq_pipe"), ("k_zq_spec", "k_zq_spec"), ("k_zq_coop", "k_zq_coop"), ("k4_zq_coop", "k4_zq_coop"), ("k_zq<256", "k_zq_keyed"), ("k_zq<512", "k_zq_chain"),
          ("k_loglik<256, true>", "k_loglik_pair"), ("k_loglik<256, false>", "k_loglik_lkh"),
          ("k_loglik_tab<256, true>", "k_loglik_pair"), ("k_loglik_tab<256, false>", "k_loglik_lkh"), ("k4_zq<256", "k4_zq_keyed")]
 
@@ -52,9 +54,11 @@ traffic = {k: int(fetch.get(k, 0) * 1024 * factor + write.get(k, 0) * 1024) for 
 # the replay schedule's update_ZQ is a phase of launches (k_tapef, the block resolution -- k_zq_blocks: one launch for all blocks, or
 # k_zq_block: one per block --, k_zq_at): its bytes per SWEEP = all those launches' bytes / number of sweeps (= k_zq_at launches)
 if "k_zq_at" in TOTALS["FETCH_SIZE"]:
+    # round 3: the phase = expected counts, accept-bit tables, probes, the sweep (the walks' maps are a few hundred KB: left out, their kernels
+    # also serve update_P); whatever sweeps fell through to the block resolver add k_tapef + k_zq_blocks / k_zq_block
     nsweep = TOTALS["FETCH_SIZE"]["k_zq_at"][1]
     tot = 0.0
-    for k in ("k_tapef", "k_zq_blocks", "k_zq_block", "k_zq_at"):
+    for k in ("k_zexpect", "k_wk_table_Z", "k_zq_probe", "k_zs_band", "k_zs_offs", "k_tapef", "k_zq_blocks", "k_zq_block", "k_zq_at"):
         tot += TOTALS["FETCH_SIZE"].get(k, (0, 0))[0] * 1024 * factor + TOTALS["WRITE_SIZE"].get(k, (0, 0))[0] * 1024
     traffic["update_ZQ_replay"] = int(tot / nsweep)
     for k in ("k_zq_blocks", "k_zq_block"):
