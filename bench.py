@@ -178,6 +178,36 @@ def cpu_baseline(geno, K, seeds):
     return {"value": round(1.0 / dt, 6), "unit": "iterations/s", "cores": 1, "kind": "port", "sample": sample, "s_per_iter": dt}
 
 
+def cpu_baseline_concurrent(geno, K, seeds, nproc=8):
+    """what a host gives the 8-chain configurations -- `nproc` single-chain reference processes side by side
+    (the reference is single threaded: `-c 8` runs its chains back to back; eight processes are the best a user can do)."""
+    N, L, _ = geno.shape
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    if not os.path.exists(exe):
+        return None
+    nproc = max(1, min(nproc, os.cpu_count() or 1))
+    iters = 3
+    with tempfile.NamedTemporaryFile(suffix=".u8", delete=False) as f:
+        np.where(geno < 0, 255, geno).astype(np.uint8).tofile(f)
+        path = f.name
+    try:
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([exe, path, str(N), str(L), str(K), str(iters)] + [str(s) for s in multichain.rank_seeds(seeds, r)],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for r in range(nproc)]
+        outs = [p.communicate(timeout=1500)[1] for p in procs]
+        wall = time.perf_counter() - t0
+    finally:
+        os.unlink(path)
+    meds = []
+    for o in outs:
+        per = sorted(json.loads(o.decode().strip().splitlines()[-1])["per_iter_s"])
+        meds.append(per[len(per) // 2])
+    return {"value": round(sum(1.0 / m for m in meds), 6), "unit": "chain-iterations/s", "cores": nproc, "kind": "reference",
+            "sample": f"{nproc} reference processes at once (seeds of ranks 0..{nproc - 1}), chain init + {iters} iterations each at N={N} L={L} K={K}; "
+                      "value = sum over processes of 1 / median iteration time",
+            "s_per_iter_median_each": [round(m, 4) for m in meds], "wall_s": round(wall, 1)}
+
+
 def chain_worker(workload, rank, steps, device, rendezvous):
     """a worker PROCESS of the several-chains-on-one-GPU leg: its own context on `device`, waits for the go file, runs `steps` iterations"""
     w = WORKLOADS[workload]
@@ -393,9 +423,10 @@ def main():
         ch.close()
 
     if rank == 0:
-        cpu = None
+        cpu = cpu8 = None
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(geno, K, seeds)
+            cpu8 = cpu_baseline_concurrent(geno, K, seeds)
         head = out["replay"]
         copy_gbs = round(capi.copy_bandwidth(local), 1)  # the fraction against a measured device-to-device copy as well (16-byte accesses)
         for o in out.values():
@@ -409,7 +440,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": w["name"], "N": N, "L": L, "K": K, "ploidy": P, "mode": 2, "rng_schedule": "replay",
                        "chains": world, "parallelism": f"{world} independent chain(s), one per GPU"},
-            "roofline": head["roofline"], "cpu_baseline": cpu,
+            "roofline": head["roofline"], "cpu_baseline": cpu, "cpu_baseline_8_processes": cpu8,
             "speedup_vs_cpu": (round(head["value"] / world / cpu["value"], 2) if cpu else None),
             "kernels_ms": head["kernels_ms"], "kernels_ms_per_step": head["kernels_ms_per_step"], "iteration_frac_of_hbm": head["iteration_frac_of_hbm"],
             "gelman_rubin": head["gelman_rubin"],
@@ -425,6 +456,8 @@ def main():
         if world == 1 and not args.no_tetra:
             if not args.no_concurrent:
                 line["concurrent_chains"] = concurrent_chains_leg(geno, an, mi, K, local, max(10, args.steps // 4), args.workload)
+                if cpu8 and line["concurrent_chains"].get("processes"):  # several chains on ONE GPU against eight host cores
+                    line["concurrent_chains"]["processes"]["vs_cpu_8_processes"] = round(line["concurrent_chains"]["processes"]["chain_iterations_per_s"] / cpu8["value"], 1)
             line["ploidy4"] = tetra_leg(local, max(4, args.steps // 10), 2, not args.no_cpu)
         print(json.dumps(line), flush=True)
     if world > 1:

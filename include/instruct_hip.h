@@ -124,9 +124,9 @@ int isg_keyed_layout(isg_ctx *ctx, uint64_t out[9]);
  * seqdata int32 [N][L][4]: the sorted distinct allele codes observed for (individual, locus) in the first
  * alleleid[i][j] entries (SEQDATA.seqdata / SEQDATA.alleleid as transform_data2 leaves them,
  * data_interface.c:571-669; alleleid 0 = missing).  cfg.P = 4; both schedules.  Keyed layout for ploidy 4
- * (amb = number of (individual, locus) pairs with 2 or 3 distinct alleles, rank = their order i-major):
+ * (amb = number of (individual, locus) pairs with 2 or 3 distinct alleles -- allotetraploid: 2, 3 or 4 --, rank = their order i-major):
  *   0 alpha | 1 + rank  initial_geno | ZI0 = 1 + amb, ZQ(init) of i at ZI0 + i SZ, SZ = 4 L + 16 K + 16
- *   B = B0 + t BLK, B0 = ZI0 + N SZ:  B + (k L + j) SP  update_P_auto (SP = 16 Amax + 16) | B + offS  update_S_POP
+ *   B = B0 + t BLK, B0 = ZI0 + N SZ:  B + (k L + j) SP  update_P_auto (SP = 16 Amax + 16; allotetraploid: both subgenomes' Dirichlets, SP = 32 Amax + 32) | B + offS  update_S_POP
  *   (offS = K L SP) | B + offZ + i SZ  update_ZQ (offZ = offS + 4 K) | B + offGE + rank  update_geno
  *   (offGE = offZ + N SZ) | BLK = offGE + amb + 4;  isg_keyed_layout: {SP, SZ, ZI0, B0, offS, offGE, offZ, offGE, BLK}
  * The generic entry points then run the ploidy-4 sweeps:

@@ -4073,6 +4073,15 @@ extern "C" int isg_get_poly_gs(isg_ctx *c, int32_t *gs, int32_t *gcount /* [L] g
 extern "C" int isg_get_poly_freq2(isg_ctx *c, double *f) /* [K][L][Amax]: the second subgenome's allele frequencies (UPMCMC.freq2, -ap 0) */
 {
 	if (!c->poly || !c->poly->p.allo) return fail("isg_get_poly_freq2: not an allotetraploid context");
+	if (!c->poly->freq_host) { /* drawn on the device (keyed schedule) */
+		const int L = c->cfg.L, K = c->cfg.K, A = c->Amax, KP = c->poly->p.KP;
+		HIPCHK(hipSetDevice(c->cfg.device));
+		HIPCHK(hipMemcpyAsync(c->freq_stage.data(), c->poly->p.freq2, sizeof(double) * (size_t)L * A * KP, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		for (int k = 0; k < K; k++)
+			for (int j = 0; j < L; j++)
+				for (int a = 0; a < A; a++) c->poly->freq2_h[((size_t)k * L + j) * A + a] = c->freq_stage[((size_t)j * A + a) * KP + k];
+	}
 	memcpy(f, c->poly->freq2_h.data(), sizeof(double) * c->poly->freq2_h.size());
 	return 0;
 }

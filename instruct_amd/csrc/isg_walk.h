@@ -314,6 +314,30 @@ ISG_HD int wk_nextset(const unsigned *row, int nwords, int X)
 	return -1;
 }
 
+/* The same through a 64-bit window (the row has a word beyond nwords: an accepted attempt is almost never further than 33 columns away, so
+ * the loop above is the rare path), and whether a row of flags has a bit set in [X, result] (urow: null = no such row). */
+ISG_HD int wk_nextset_flag(const unsigned *row, const unsigned *urow, int nwords, int X, int *flag)
+{
+	const int w = X >> 5, sh = X & 31;
+	if (w >= nwords) return -1;
+	const unsigned long long v = ((((unsigned long long)row[w + 1]) << 32) | (unsigned long long)row[w]) >> sh;
+	if (v) {
+		const int c = __builtin_ctzll(v);
+		if (X + c >= (nwords << 5)) return -1;
+		if (urow) {
+			const unsigned long long uv = ((((unsigned long long)urow[w + 1]) << 32) | (unsigned long long)urow[w]) >> sh;
+			if (uv & ((2ull << c) - 1ull)) *flag = 1;
+		}
+		return X + c;
+	}
+	const int X1 = wk_nextset(row, nwords, X);
+	if (X1 >= 0 && urow) {
+		const int U1 = wk_nextset(urow, nwords, X);
+		if (U1 >= 0 && U1 <= X1) *flag = 1;
+	}
+	return X1;
+}
+
 /* ---------------------------------------------------------------------------------------------------------------- */
 /* wk_table                                                                                                           */
 /* ---------------------------------------------------------------------------------------------------------------- */
@@ -449,12 +473,8 @@ ISG_HD void wk_table_body(const WkTableArgs A, int wg, int nthreads, unsigned ch
 		for (int col = t; col < W; col += nthreads) {
 			int X = col, bad = 0, unc = 0;
 			for (int m = 0; m < ng; m++) {
-				const int X1 = wk_nextset(rows + m * nw, nwv, X);
+				const int X1 = wk_nextset_flag(rows + m * nw, interval ? rows + (ng + m) * nw : (const unsigned *)0, nwv, X, &unc);
 				if (X1 < 0) { bad = 1; break; }
-				if (interval) {
-					const int U1 = wk_nextset(rows + (ng + m) * nw, nwv, X);
-					if (U1 >= 0 && U1 <= X1) unc = 1;
-				}
 				X = X1;
 			}
 			const int c = X - col;

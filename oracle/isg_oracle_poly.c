@@ -284,6 +284,7 @@ static void update_P_allo(void) /* poly_geno.c:441-518: per (cluster, locus) the
 	for (i = 0; i < K; i++)
 		for (j = 0; j < L; j++) {
 			for (k = 0; k < allelenum[j]; k++) tmp[k] = (double)cnt[((long)i * L + j) * Amax + k];
+			rng_seek(ky_B0 + ky_iter * ky_BLK + ((uint64_t)i * L + j) * ky_SP); /* (keyed: both Dirichlets from this position on) */
 			rdirich(tmp, allelenum[j], &FREQ(i, j, 0), 1.0);
 			for (k = 0; k < allelenum[j]; k++) tmp[k] = (double)cnt2[((long)i * L + j) * Amax + k];
 			rdirich(tmp, allelenum[j], &FREQ2(i, j, 0), 1.0);
@@ -741,7 +742,6 @@ int main(int argc, char **argv)
 	if (argc >= 17) { g_math = atoi(argv[15]); g_accum = atoi(argv[16]); }
 	if (argc >= 18) g_keyed = atoi(argv[17]);
 	if (argc == 19) g_allo = atoi(argv[18]);
-	if (g_allo && g_keyed) { fprintf(stderr, "the keyed schedule is not defined for -ap 0\n"); return 2; }
 	K = atoi(argv[3]); u = atol(argv[6]); b = atol(argv[7]); t = atoi(argv[8]); e = atoi(argv[9]); r = atoi(argv[10]); jj = atoi(argv[11]);
 	s1 = atoi(argv[12]); s2 = atoi(argv[13]); s3 = atoi(argv[14]);
 	back_refl = e;
@@ -774,10 +774,10 @@ int main(int argc, char **argv)
 	gen_polyinfo();
 	{ /* keyed layout; the chain origin is the stream state when the chain starts (after read_init's draws) */
 		uint64_t amb = 0;
-		for (i = 0; i < N * L; i++) amb += (alleleid[i] == 2 || alleleid[i] == 3);
+		for (i = 0; i < N * L; i++) amb += (alleleid[i] == 2 || alleleid[i] == 3 || (g_allo && alleleid[i] == 4)); /* loci whose genotype is drawn */
 		isg_wh_tables_init(&g_tab);
 		g_origin.s1 = (uint32_t)sd1; g_origin.s2 = (uint32_t)sd2; g_origin.s3 = (uint32_t)sd3;
-		ky_SP = 16 * (uint64_t)Amax + 16; ky_SZ = 4 * (uint64_t)L + 16 * (uint64_t)K + 16;
+		ky_SP = (g_allo ? 2 : 1) * (16 * (uint64_t)Amax + 16); ky_SZ = 4 * (uint64_t)L + 16 * (uint64_t)K + 16;
 		ky_G0 = 1; ky_ZI0 = 1 + amb; ky_B0 = ky_ZI0 + (uint64_t)N * ky_SZ;
 		ky_offS = (uint64_t)K * L * ky_SP; ky_offZ = ky_offS + 4 * (uint64_t)K; ky_offGE = ky_offZ + (uint64_t)N * ky_SZ;
 		ky_BLK = ky_offGE + amb + 4;

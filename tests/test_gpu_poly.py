@@ -29,6 +29,7 @@ EXTRA = {
     "x_wide": (3, 66500, 3, 3, 0.05, 2, 1, 1, 1, 1, 1, (26, 12, 2004)),   # more loci than 128 workgroups x 512 lanes: several passes
     "x_a10k3": (60, 12, 3, 10, 0.05, 2, 1, 1, 1, 1, 1, (27, 13, 2005)),   # microsatellite-like: 10 alleles, 715 genotypes per locus
     "x_spec": (120, 2500, 4, 4, 0.05, 3, 1, 1, 1, 1, 1, (28, 14, 2006)),    # clusters of ~2400 draws: the interval resolver settles update_ZQ itself
+    "x_zz_a16k3": (80, 8, 3, 16, 0.05, 2, 1, 1, 1, 1, 1, (29, 15, 2007)),   # the allele cap: 16 alleles, 3876 genotypes per locus
 }
 
 
@@ -157,6 +158,7 @@ ALLO_EXTRA = {
     "xa_a6k2": (30, 24, 2, 6, 0.05, 3, 1, 1, 0, 1, 1, (32, 8, 2000)),    # 6 alleles: 441 genotypes per locus
     "xa_a3k9": (20, 700, 9, 3, 0.10, 2, 1, 1, 1, 1, 1, (33, 9, 2001)),   # several workgroups per individual, K > 8
     "xa_a9k3": (50, 10, 3, 9, 0.05, 2, 1, 1, 1, 1, 1, (34, 10, 2002)),   # 9 alleles: 2673 genotypes per locus
+    "xa_zz_a16k2": (50, 6, 2, 16, 0.05, 2, 1, 1, 1, 1, 1, (35, 11, 2003)),  # the allele cap: 16 alleles, 18496 genotypes per locus
 }
 
 
@@ -210,11 +212,24 @@ def test_allotetraploid_matches_reference_golden(name):
             assert x == y or (x != x and y != y) or abs(x - y) <= 1e-9 * max(abs(x), abs(y)), (g, w)
 
 
-def test_allotetraploid_keyed_schedule_is_refused():
-    from instruct_amd import capi, synth
-    obs, alleleid, allelenum = synth.code_tetraploid(gu.make_golden.allo_data_for("ta3_a2"))
-    with pytest.raises(capi.IsgError, match="keyed schedule is not defined for allotetraploids"):
-        capi.HipPolyChain(obs, alleleid, allelenum, 3, rng_sched=1, allo=True)
+@pytest.mark.parametrize("name", sorted(ALLO) + sorted(ALLO_EXTRA))
+def test_allotetraploid_keyed_schedule_bit_identical_to_oracle_keyed(name, tmp_path):
+    """-ap 0 in the keyed schedule (layout in include/instruct_hip.h: a (cluster, locus) slot holds both subgenomes' Dirichlets,
+    loci with four distinct alleles count as drawn): every sweep equal to the oracle's keyed chain"""
+    from instruct_amd import synth
+    extra = name in ALLO_EXTRA
+    cfg = ALLO_EXTRA[name] if extra else ALLO[name]
+    raw = synth.raw_alleles(cfg[0], cfg[1], cfg[2], 4, cfg[3], cfg[4], 20260401 + sorted(ALLO_EXTRA).index(name)) if extra else gu.make_golden.allo_data_for(name)
+    txt = str(tmp_path / (name + ".txt"))
+    synth.write_text_polyploid(txt, raw)
+    N, L, K, A, miss, u, b, t, e, r, j, seeds = cfg
+    out = str(tmp_path / (name + ".key"))
+    assert subprocess.call([DUMP, txt, out] + [str(x) for x in (K, N, L, u, b, t, e, r, j) + tuple(seeds)] + ["1", "1", "1", "1"]) == 0
+    want = [l for l in gu.parse(out) if l.startswith("it ") or l.startswith("chain zqinit")]
+    got = hip_lines(name, cfg, raw, sched=1, allo=True)
+    assert len(got) == len(want) == 1 + 6 * u
+    for g, w in zip(got, want):
+        assert _norm(_noseeds(g)) == _norm(_noseeds(w))
 
 
 def _noseeds(line):
