@@ -107,6 +107,16 @@ def roofline_of(prof, steps, N, L, P, nvalid_copies, extra, traffic, phase_bytes
     tot = {k: ms for k, (ms, n) in prof.items()}
     dom = max(tot, key=tot.get)
     ms, n = prof[dom]
+    empty = 0
+
+    def real_launches(k, cnt):
+        # k_zq_at is also launched behind every blind probe round of the interval resolver and returns at once while the trajectory still
+        # holds uncertain bytes (a few microseconds): ONE launch per iteration is the sweep, the average is taken over those
+        return steps if (k == "k_zq_at" and cnt > steps) else cnt
+
+    if real_launches(dom, n) != n:
+        empty = n - steps
+        n = steps
     alg = kernel_alg_bytes(dom, N, L, P, nvalid_copies, extra)
     avg_s = ms / n * 1e-3
     out = {"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(ms / n, 4), "launches_per_step": round(n / steps, 2),
@@ -117,6 +127,8 @@ def roofline_of(prof, steps, N, L, P, nvalid_copies, extra, traffic, phase_bytes
         out.update(achieved=round(gbs, 3), frac=round(gbs / HBM_PEAK_GBS, 6))
     else:
         out.update(achieved=None, frac=None)
+    if empty:
+        out["early_exit_launches_per_step"] = round(empty / steps, 2)
     if dom.startswith("k_wk_table"):
         out["note"] = ("accept-bit tables of the walk engine: VALU work (one rgamma attempt decision per (gamma, window column)), hardly any HBM traffic -- "
                        "its algorithmic bytes are the table bytes it writes; the streaming sweep is `sweep_kernel`, the whole phase `phase`")
@@ -128,6 +140,7 @@ def roofline_of(prof, steps, N, L, P, nvalid_copies, extra, traffic, phase_bytes
     sk = next((k for k in ("k_zq_at", "k_zq_keyed", "k4_zq_keyed", "k4_zq_coop", "k4_zq") if k in prof), None)
     if sk:
         sms, sn = prof[sk]
+        sn = real_launches(sk, sn)
         sb = kernel_alg_bytes(sk, N, L, P, nvalid_copies, extra)
         out["sweep_kernel"] = {"kernel": sk, "avg_launch_ms": round(sms / sn, 4), "alg_bytes_per_launch": sb,
                                "achieved": round(sb / (sms / sn * 1e-3) / 1e9, 3), "frac": round(sb / (sms / sn * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),

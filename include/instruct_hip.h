@@ -186,16 +186,18 @@ int isg_zq_resolve_plan(int units, double mu, double sigma, double a, double sha
  * one parallel pass with every Dirichlet's consumption checked.  A sweep this path cannot settle (many small clusters: every
  * candidate uncertain) goes to the block resolver / chain kernels above; INSTRUCT_ZQ_SPEC_RESOLVE=0 disables it.  Diagnostics:
  * out = {sweeps tried, settled, lost (handed on), probes of the last sweep, fail bits of the last sweep (1 window missed, 2 irregular
- * byte, 16 probe list full, 32 consumption check, 64 rounds did not settle), probe rounds of the last sweep, bytes of the accept-bit tables, segments} */
-int isg_zq_spec_stats(isg_ctx *ctx, long out[8]);
+ * byte, 16 probe list full, 32 consumption check, 64 rounds did not settle), probe rounds of the last sweep, bytes of the accept-bit tables, segments,
+ * fail bits of all lost sweeps together, sweeps redone at once with wider windows after a missed window} */
+int isg_zq_spec_stats(isg_ctx *ctx, long out[10]);
 /* Replay-schedule update_P on the device (instruct_amd/csrc/isg_walk_hip.inc): the start position of every Dirichlet of
  * mcmc.c:846-857 / poly_geno.c:426-434 is resolved by the walk engine (accept bits of every (gamma, stream position) on the
  * whole chip, hierarchical composition of the blocks' offset maps), then all Dirichlets are drawn at once and each is checked
- * to have consumed what the resolution said.  A sweep whose windows were missed is drawn by the sequential host loop instead
- * (same values).  INSTRUCT_P_DEVICE=0 selects the host loop always.  Diagnostics:
- * out = {sweeps on the device, sweeps that fell back to the host loop, segments, blocks, table bytes, 1000 sigma (spread of the
- * rejections per gamma the windows assume), 1000 scale (measured / predicted drift), 1000 window half-width in sigma} */
-int isg_p_device_stats(isg_ctx *ctx, long out[8]);
+ * to have consumed what the resolution said.  A sweep whose windows were missed is resolved once more with wider windows and, if
+ * that fails too, drawn by the sequential host loop instead (same values).  INSTRUCT_P_DEVICE=0 selects the host loop always.
+ * Diagnostics: out = {sweeps on the device, sweeps that fell back to the host loop, segments, blocks, table bytes, 1000 sigma (spread
+ * of the rejections per gamma the windows assume), 1000 scale (measured / predicted drift), 1000 window half-width in sigma, sweeps
+ * resolved a second time with wider windows, runs of the engine that failed} */
+int isg_p_device_stats(isg_ctx *ctx, long out[10]);
 
 /* per-kernel device timing with HIP events on the launch stream (bench.py roofline) */
 int isg_profile_enable(isg_ctx *ctx, int on);

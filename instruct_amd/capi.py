@@ -238,15 +238,15 @@ class HipChain:
 
     def zq_spec_stats(self):
         """replay update_ZQ by shape intervals (isg_spec_hip.inc): sweeps tried / settled / lost, probes and fail bits of the last one"""
-        out = (C.c_long * 8)()
+        out = (C.c_long * 10)()
         self._chk(self.lib.isg_zq_spec_stats(self.h, out))
-        return dict(zip(("tried", "settled", "lost", "probes", "fail_bits", "rounds", "table_bytes", "segments"), out))
+        return dict(zip(("tried", "settled", "lost", "probes", "fail_bits", "rounds", "table_bytes", "segments", "lost_fail_bits", "retried"), out))
 
     def p_device_stats(self):
         """replay update_P on the device (walk engine): sweeps done there / by the host loop, plan size, window statistics"""
-        out = (C.c_long * 8)()
+        out = (C.c_long * 10)()
         self._chk(self.lib.isg_p_device_stats(self.h, out))
-        return dict(zip(("device_sweeps", "host_sweeps", "segments", "blocks", "table_bytes", "sigma_x1000", "scale_x1000", "kwin_x1000"), out))
+        return dict(zip(("device_sweeps", "host_sweeps", "segments", "blocks", "table_bytes", "sigma_x1000", "scale_x1000", "kwin_x1000", "retried", "failed_runs"), out))
 
     def gather_convg(self, rank, world, id_path, mine):
         """ncclAllGather of this chain's log-likelihood samples (RCCL on device buffers) -> [world * n]"""

@@ -73,6 +73,11 @@ struct DevView {
 	 *   lftab [L][Amax][K]                log freq                          (copies whose partner sits in another cluster)
 	 *   lltab [50][L][Amax][Amax][K]      log genofreq(generation, f0, f1)  (both copies in cluster k); null if too large */
 	double *lftab, *lltab;
+	/* mode 2: the same terms as the two integers isg_acc2 sums, {rint(v 2^20), rint((v - h 2^-20) 2^51)}, locus innermost, ONE allocation addressed
+	 * by 32-bit entry numbers: [0] = {0, 0}; 1 + ((g - 1) A A K + (a0 A + a1) K + k) Lp + j = log genofreq(g); lli_F + (a K + k) Lp + j = log freq.
+	 * h = INT_MIN marks a term isg_acc2 would flag (infinite, NaN, |v| >= 1024): m holds its flag bits. */
+	int2 *lli;
+	unsigned lli_F;
 	const double *tape;  /* replay schedule: the uniforms of the ZQ phase in stream order */
 	unsigned long long tape_len;
 	int *cnt;
@@ -476,6 +481,137 @@ __global__ void k_lltab(DevView d)
 		}
 	} else {
 		for (int g = 1; g <= 50; g++) d.lltab[(size_t)(g - 1) * per + id] = isg_log(2 * f0 * f1 * isg_scalbn(1.0, -(g - 1)));
+	}
+}
+
+/* the terms of k_lltab as isg_acc2's integers, locus innermost (one lane per (allele pair, cluster, locus): consecutive lanes write consecutive entries) */
+__device__ __forceinline__ int2 lli_entry(double v)
+{
+	if (!(v > -1024.0 && v < 1024.0)) {
+		const uint64_t u = isg_d2u(v);
+		return make_int2((int)0x80000000u, (u == 0x7ff0000000000000ULL) ? 1 : (u == 0xfff0000000000000ULL) ? 2 : 4);
+	}
+	const double hs = __builtin_rint(v * 1048576.0);
+	const double lo = isg_fma(hs, -0x1p-20, v); /* exact */
+	return make_int2((int)hs, (int)__builtin_rint(lo * 0x1p51));
+}
+__global__ void k_lltab_int(DevView d)
+{
+	const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t AAK = (size_t)d.Amax * d.Amax * d.K;
+	if (id == 0) d.lli[0] = make_int2(0, 0);
+	if (id >= AAK * d.L) return;
+	const int j = (int)(id % d.L), combo = (int)(id / d.L);
+	const int k = combo % d.K, a1 = (combo / d.K) % d.Amax, a0 = combo / d.K / d.Amax;
+	const double f0 = d.freq[((size_t)j * d.Amax + a0) * d.KP + k], f1 = d.freq[((size_t)j * d.Amax + a1) * d.KP + k];
+	if (a1 == 0) d.lli[d.lli_F + ((size_t)a0 * d.K + k) * d.Lp + j] = lli_entry(isg_log(f0));
+	int2 *out = d.lli + 1 + (size_t)combo * d.Lp + j;
+	const size_t gstride = AAK * d.Lp;
+	if (a0 == a1) { /* isg_genofreq(hom): result after g - 1 rounds of the loop */
+		double result = f0 * f0, temp = 2 * f0 * (1 - f0);
+		for (int g = 1; g <= 50; g++) {
+			out[(size_t)(g - 1) * gstride] = lli_entry(isg_log(result));
+			temp /= 2;
+			result += temp / 2;
+		}
+	} else {
+		for (int g = 1; g <= 50; g++) out[(size_t)(g - 1) * gstride] = lli_entry(isg_log(2 * f0 * f1 * isg_scalbn(1.0, -(g - 1))));
+	}
+}
+
+/* log_ld_indv (mode 2, -y 1) from the integer tables: straight-line per locus -- two entry numbers (same cluster: the genotype term at the current and,
+ * PAIR, the proposed generation; different clusters: the two allele terms; locus unused: entry 0), two 8-byte loads, 64-bit integer adds.  The sums
+ * are those k_loglik_tab forms (integer addition: any grouping), so the values are the same bits.
+ *   current  = sum A + sum over mixed loci of B + n2 log 2         A = genotype term(gc) | log f0,   B = genotype term(gp) | log f1
+ *   proposed = sum B + sum over mixed loci of A + n2 log 2         (PAIR = false: B = 0 | log f1, indvlkh = sum A + sum B + n2 log 2) */
+template <int BLOCK, bool PAIR>
+__global__ void __launch_bounds__(BLOCK) k_loglik_int(DevView d)
+{
+	constexpr int NW = BLOCK / 64, NS = PAIR ? 10 : 6;
+	__shared__ long long sm[NW * NS];
+	const int i = blockIdx.x;
+	const int gc = d.gen[i];
+	int gp = gc;
+	if (PAIR) {
+		gp = d.genprop[i];
+		if (gp == gc) return;
+	}
+	const unsigned Lp = (unsigned)d.Lp, A = (unsigned)d.Amax, K = (unsigned)d.K;
+	const unsigned gstride = A * A * K * Lp;
+	const unsigned baseC = 1u + (unsigned)(gc - 1) * gstride, dCP = (unsigned)(gp - gc) * gstride /* (mod 2^32) */, baseF = d.lli_F;
+	const int2 *T = d.lli;
+	const size_t rowb = (size_t)d.Lp * 2;
+	const uint8_t *grow = d.geno + (size_t)i * rowb;
+	const uint8_t *zrow = d.z + (size_t)i * rowb;
+	long long sAh = 0, sAm = 0, sBh = 0, sBm = 0, mAh = 0, mAm = 0, mBh = 0, mBm = 0;
+	unsigned n2 = 0, flags = 0;
+	for (unsigned j0 = threadIdx.x * ISG_LPT; j0 < Lp; j0 += BLOCK * ISG_LPT) {
+		const uint2 g = *(const uint2 *)(grow + (size_t)j0 * 2);
+		const uint2 zz = *(const uint2 *)(zrow + (size_t)j0 * 2);
+#pragma unroll
+		for (int l = 0; l < ISG_LPT; l++) {
+			const unsigned gw = (l < 2) ? g.x : g.y, zw = (l < 2) ? zz.x : zz.y;
+			const unsigned a0 = (gw >> (16 * (l & 1))) & 0xff, a1 = (gw >> (16 * (l & 1) + 8)) & 0xff;
+			const unsigned z0 = (zw >> (16 * (l & 1))) & 0xff, z1 = (zw >> (16 * (l & 1) + 8)) & 0xff;
+			const bool valid = (a0 != 0xff), same = (z0 == z1);
+			const unsigned j = j0 + (unsigned)l;
+			const unsigned og = baseC + ((a0 * A + a1) * K + z0) * Lp + j;
+			const unsigned o0 = baseF + (a0 * K + z0) * Lp + j, o1 = baseF + (a1 * K + z1) * Lp + j;
+			unsigned offA = same ? og : o0;
+			unsigned offB = PAIR ? (same ? og + dCP : o1) : (same ? 0u : o1);
+			offA = valid ? offA : 0u;
+			offB = valid ? offB : 0u;
+			int2 ea = T[offA], eb = T[offB];
+			if (ea.x == (int)0x80000000u || eb.x == (int)0x80000000u) { /* (never with frequencies in (0, 1); the terms isg_acc2 flags) */
+				/* bits 0..7: flags of the current generation's total, 8..15: of the proposed one's (each takes the terms listed above) */
+				if (ea.x == (int)0x80000000u) { flags |= (unsigned)ea.y | ((PAIR && !same) ? (unsigned)ea.y << 8 : 0u); ea = make_int2(0, 0); }
+				if (eb.x == (int)0x80000000u) { flags |= (PAIR ? (unsigned)eb.y << 8 : 0u) | ((!PAIR || !same) ? (unsigned)eb.y : 0u); eb = make_int2(0, 0); }
+			}
+			sAh += ea.x; sAm += ea.y;
+			sBh += eb.x; sBm += eb.y;
+			if (PAIR) {
+				mAh += same ? 0 : ea.x; mAm += same ? 0 : ea.y;
+				mBh += same ? 0 : eb.x; mBm += same ? 0 : eb.y;
+			}
+			n2 += (valid && !same && a0 != a1) ? 1u : 0u;
+		}
+	}
+	/* block sums */
+	long long v[NS];
+	v[0] = sAh; v[1] = sAm; v[2] = sBh; v[3] = sBm; v[4] = (long long)n2; v[5] = (long long)flags;
+	if (PAIR) { v[6] = mAh; v[7] = mAm; v[8] = mBh; v[9] = mBm; }
+#pragma unroll
+	for (int q = 0; q < NS; q++) {
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const long long w = __shfl_down(v[q], o, 64);
+			v[q] = (q == 5) ? (v[q] | w) : v[q] + w;
+		}
+		if (lane_id() == 0) sm[(threadIdx.x >> 6) * NS + q] = v[q];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		long long r[NS];
+		for (int q = 0; q < NS; q++) {
+			r[q] = 0;
+			for (int w = 0; w < NW; w++) r[q] = (q == 5) ? (r[q] | sm[w * NS + q]) : r[q] + sm[w * NS + q];
+		}
+		const int2 l2 = lli_entry(isg_log(2.0));
+		isg_acc2 tc;
+		tc.flags = (uint32_t)r[5] & 0xffu;
+		if (PAIR) {
+			isg_acc2 tp;
+			tp.flags = ((uint32_t)r[5] >> 8) & 0xffu;
+			tc.hi = r[0] + r[8] + r[4] * l2.x; tc.lo = r[1] + r[9] + r[4] * l2.y;
+			tp.hi = r[2] + r[6] + r[4] * l2.x; tp.lo = r[3] + r[7] + r[4] * l2.y;
+			const double lc = isg_acc2_value(&tc), lp = isg_acc2_value(&tp);
+			const double mh = isg_exp(lp - lc);
+			const double thr = (1 > mh) ? mh : 1; /* MIN2(1, mhratio), mcmc.h:10 */
+			if (d.uacc[i] < thr) d.gen[i] = gp;
+		} else {
+			tc.hi = r[0] + r[2] + r[4] * l2.x; tc.lo = r[1] + r[3] + r[4] * l2.y;
+			d.indvlkh[i] = isg_acc2_value(&tc);
+		}
 	}
 }
 
@@ -3079,12 +3215,19 @@ extern "C" int isg_ctx_create(const isg_config *cfg, const int32_t *allelenum, c
 	d.KPF = (K + 3) & ~3;
 	DALLOC(d.freqf, float, (size_t)Lp * Amax * d.KPF);
 	d.lftab = d.lltab = nullptr;
+	d.lli = nullptr;
+	d.lli_F = 0;
 	if (cfg->type_freq == 1 || cfg->mode == 0) { /* (-y 0 mixes the frequencies with the individual's qq: no tables) */
 		const char *e = getenv("INSTRUCT_LL_TABLES");
 		if (!(e && atoi(e) == 0)) {
 			DALLOC(d.lftab, double, (size_t)L * Amax * K);
 			const size_t ent = (size_t)50 * L * Amax * Amax * K;
-			if (cfg->mode == 2 && ent * sizeof(double) <= ((size_t)1 << 30)) { DALLOC(d.lltab, double, ent); } /* (mode 3: unclamped initial generations) */
+			const char *ei = getenv("INSTRUCT_LL_INT");
+			const size_t enti = 1 + (size_t)50 * Lp * Amax * Amax * K + (size_t)Lp * Amax * K; /* the integer form, locus innermost (k_loglik_int) */
+			if (cfg->mode == 2 && !(ei && atoi(ei) == 0) && enti * sizeof(int2) <= ((size_t)1 << 30)) {
+				DALLOC(d.lli, int2, enti);
+				d.lli_F = (unsigned)(1 + (size_t)50 * Lp * Amax * Amax * K);
+			} else if (cfg->mode == 2 && ent * sizeof(double) <= ((size_t)1 << 30)) { DALLOC(d.lltab, double, ent); } /* (mode 3: unclamped initial generations) */
 			if (cfg->mode == 4) { /* one slot: log genofreq_inbreedcoff.  Mode 4 has no table-free path: up to half of what the device has free */
 				size_t fr = 0, tot = 0;
 				if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)1 << 31;
@@ -3224,7 +3367,7 @@ extern "C" void isg_ctx_destroy(isg_ctx *c)
 	}
 	inbreed_free(c);
 	DevView &d = c->d;
-	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(d.lftab); (void)hipFree(d.lltab); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(c->d_pipe); (void)hipFree(c->d_spop); (void)hipFree(d.cnt);
+	(void)hipFree((void *)d.geno); (void)hipFree(d.z); (void)hipFree((void *)d.allelenum); (void)hipFree((void *)d.nvalid); (void)hipFree(d.freq); (void)hipFree(d.freqf); (void)hipFree(d.lftab); (void)hipFree(d.lltab); (void)hipFree(d.lli); (void)hipFree(c->d_tape); (void)hipFree((void *)d.rankwave); (void)hipFree(c->d_coop); (void)hipFree(c->d_pipe); (void)hipFree(c->d_spop); (void)hipFree(d.cnt);
 	(void)hipFree(d.qq); (void)hipFree(c->d_qqsave); (void)hipFree(d.qqnum); (void)hipFree(d.gen); (void)hipFree(d.genprop); (void)hipFree(d.uacc); (void)hipFree(d.indvlkh);
 	(void)hipFree((void *)d.tab); (void)hipFree(c->d_pos); (void)hipFree(c->d_err); (void)hipFree(c->d_S); (void)hipFree(c->d_Fprop); (void)hipFree(c->d_state); (void)hipFree(c->d_ratios); (void)hipFree(c->d_total);
 	prof_collect(c);
@@ -3272,7 +3415,12 @@ static int refresh_freqf(isg_ctx *c)
 	prof_begin(c);
 	hipLaunchKernelGGL(k_freqf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d);
 	prof_end(c, "k_freqf");
-	if (d.lftab) {
+	if (d.lli) { /* mode 2: the integer tables are all the likelihood sweeps read */
+		const size_t per = (size_t)d.L * d.Amax * d.Amax * d.K;
+		prof_begin(c);
+		hipLaunchKernelGGL(k_lltab_int, dim3((unsigned)((per + 127) / 128)), dim3(128), 0, c->stream, d);
+		prof_end(c, "k_lltab");
+	} else if (d.lftab) {
 		const size_t per = (size_t)d.L * d.Amax * d.Amax * d.K;
 		prof_begin(c);
 		hipLaunchKernelGGL(k_lltab, dim3((unsigned)((per + 127) / 128)), dim3(128), 0, c->stream, d);
@@ -3539,7 +3687,8 @@ extern "C" int isg_update_G(isg_ctx *c)
 	hipLaunchKernelGGL(k_gprop<1024>, dim3(1), dim3(1024), 0, c->stream, d, (const double *)d_S, base, is_keyed(c) ? 1 : 0, c->d_pos);
 	prof_end(c, "k_gprop");
 	prof_begin(c);
-	if (d.lltab) hipLaunchKernelGGL((k_loglik_tab<256, true>), dim3(d.N), dim3(256), 0, c->stream, d);
+	if (d.lli && d.mode == 2) hipLaunchKernelGGL((k_loglik_int<256, true>), dim3(d.N), dim3(256), 0, c->stream, d);
+	else if (d.lltab) hipLaunchKernelGGL((k_loglik_tab<256, true>), dim3(d.N), dim3(256), 0, c->stream, d);
 	else hipLaunchKernelGGL((k_loglik<256, true>), dim3(d.N), dim3(256), 0, c->stream, d);
 	prof_end(c, "k_loglik_pair");
 	HIPCHK(hipGetLastError());
@@ -3762,7 +3911,8 @@ extern "C" int isg_cal_lkh(isg_ctx *c)
 	if (c->cfg.mode == 5) return indiv_cal_lkh_F(c);
 	DevView &d = c->d;
 	prof_begin(c);
-	if (d.lltab || (d.lftab && d.mode == 1)) hipLaunchKernelGGL((k_loglik_tab<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
+	if (d.lli && d.mode == 2) hipLaunchKernelGGL((k_loglik_int<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
+	else if (d.lltab || (d.lftab && d.mode == 1)) hipLaunchKernelGGL((k_loglik_tab<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
 	else hipLaunchKernelGGL((k_loglik<256, false>), dim3(d.N), dim3(256), 0, c->stream, d);
 	prof_end(c, "k_loglik_lkh");
 	prof_begin(c);
@@ -4214,9 +4364,9 @@ extern "C" int isg_store_fetch(isg_ctx *c, double *qq, double *qq2, double *indv
 }
 
 extern "C" long isg_zq_fallbacks(isg_ctx *c) { return c->zq_fallbacks; }
-extern "C" int isg_zq_spec_stats(isg_ctx *c, long out[8])
+extern "C" int isg_zq_spec_stats(isg_ctx *c, long out[10])
 {
-	for (int k = 0; k < 8; k++) out[k] = 0;
+	for (int k = 0; k < 10; k++) out[k] = 0;
 	if (!c->zspec) return 0;
 	out[0] = c->zspec->sweeps;
 	out[1] = c->zspec->done;
@@ -4226,11 +4376,13 @@ extern "C" int isg_zq_spec_stats(isg_ctx *c, long out[8])
 	out[5] = (long)c->zspec->last_rounds;
 	out[6] = (long)c->zspec->walk.plan.table_bytes;
 	out[7] = (long)c->zspec->walk.plan.seg.size();
+	out[8] = (long)c->zspec->lost_fail;
+	out[9] = c->zspec->retried;
 	return 0;
 }
-extern "C" int isg_p_device_stats(isg_ctx *c, long out[8])
+extern "C" int isg_p_device_stats(isg_ctx *c, long out[10])
 {
-	for (int k = 0; k < 8; k++) out[k] = 0;
+	for (int k = 0; k < 10; k++) out[k] = 0;
 	if (!c->pdev) return 0;
 	const WalkRun &w = c->pdev->walk;
 	out[0] = c->pdev->sweeps - c->pdev->fallbacks;
@@ -4241,6 +4393,8 @@ extern "C" int isg_p_device_stats(isg_ctx *c, long out[8])
 	out[5] = (long)(1000.0 * w.sigma);
 	out[6] = (long)(1000.0 * w.scale);
 	out[7] = (long)(1000.0 * w.kwin);
+	out[8] = c->pdev->retried;
+	out[9] = w.fails;
 	return 0;
 }
 extern "C" int isg_profile_enable(isg_ctx *c, int on) { c->prof = on != 0; return 0; }

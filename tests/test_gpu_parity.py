@@ -232,7 +232,7 @@ _P0 = dict(_S0, INSTRUCT_ZQ_RESOLVE_PERSIST="0")   # one launch per block instea
                                  _R0, dict(_R0, INSTRUCT_ZQ_PIPE="0"),
                                  dict(_R0, INSTRUCT_ZQ_PIPE_XCD="0"), dict(_R0, INSTRUCT_ZQ_SPEC="0"), dict(_R0, INSTRUCT_ZQ_XCD="1"),
                                  dict(_R0, INSTRUCT_ZQ_SPEC="0", INSTRUCT_ZQ_XCD="1"), dict(_R0, INSTRUCT_ZQ_COOP="0"),
-                                 {"INSTRUCT_P_DEVICE": "0"}])
+                                 {"INSTRUCT_P_DEVICE": "0"}, {"INSTRUCT_LL_INT": "0"}, {"INSTRUCT_LL_TABLES": "0"}])   # (likelihood terms: double tables / evaluated directly)
 @pytest.mark.parametrize("case", [(24, 700, 5, 0.05, 2), (6, 40000, 3, 0.02, 2), (8, 33000, 9, 0.0, 3),
                                   (10, 20000, 8, 0.03, 3), (16, 3000, 2, 0.1, 2)])
 def test_replay_zq_kernel_variants_bit_exact_vs_canonical_oracle(case, env, monkeypatch):
