@@ -47,6 +47,14 @@ def sync():
     torch.cuda.synchronize()
 
 
+def note(msg):
+    """progress on stderr (stdout carries the ONE JSON line): which leg is running, should the process ever die inside one"""
+    print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
 def timed_steps(chain, steps, warmup, world):
     """(seconds for exactly `steps` iterations, profiling off; log-likelihood samples; per-kernel profile of a second pass)"""
     import torch.distributed as dist
@@ -276,6 +284,7 @@ def concurrent_chains_leg(geno, an, mi, K, device, steps, workload):
     res["note"] = "aggregate over n chains on one GPU (threads of this process), replay schedule; not part of `value` (1 chain per GPU)"
     # (b) processes: 4 workers (the test boxes allow at most 6 processes on a GPU at once, this one included)
     nproc = 4
+    note("several chains on one GPU: %d processes" % nproc)
     with tempfile.TemporaryDirectory() as rv:
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--chain-worker", str(r), "--steps", str(steps), "--workload", workload,
                                    "--device", str(device), "--rendezvous", rv], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for r in range(nproc)]
@@ -307,6 +316,12 @@ def tetra_leg(device, steps, warmup, with_cpu):
     obs, alleleid, allelenum = synth.make_tetraploid_fast(N, L, K, A, 0.05, 20260105)
     nvalid = int((alleleid > 0).sum())
     traffic = load_traffic()
+    # the ploidy-4 kernels are timed under the diploid phase names; their counter traffic is filed under their own kernel names (profiles/traffic.json)
+    traffic4 = dict(traffic)
+    for name, own in (("k_zq_at", "k4_zq_keyed"), ("k_zexpect", "k4_zexpect"), ("k_zq_probe", "k4_zq_probe")):
+        traffic4[name] = traffic.get(own)
+    traffic4["update_ZQ_replay"] = (sum(traffic[k] for k in ("k4_zexpect", "k4_zexpect_fin", "k4_zq_keyed", "k4_zq_probe", "k_wk_table_Z")) if all(
+        k in traffic for k in ("k4_zexpect", "k4_zexpect_fin", "k4_zq_keyed", "k4_zq_probe", "k_wk_table_Z")) else None)
 
     def one(sched, nsteps):
         ch = capi.HipPolyChain(obs, alleleid, allelenum, K, back_refl=1, rng_sched=sched, device=device)
@@ -331,7 +346,7 @@ def tetra_leg(device, steps, warmup, with_cpu):
         stats = {"interval_resolver": ch.zq_spec_stats(), "update_P_device": ch.p_device_stats(), "fallback_sweeps": ch.zq_fallbacks()} if sched == capi.SCHED_REPLAY else {}
         ch.close()
         out = {"value": round(nsteps / dt, 4), "unit": "iterations/s", "ms_per_step": round(dt / nsteps * 1e3, 3),
-               "roofline": roofline_of(prof, psteps, N, L, 4, 4 * nvalid, extra, traffic, 2 * 4 * nvalid),
+               "roofline": roofline_of(prof, psteps, N, L, 4, 4 * nvalid, extra, traffic4, 2 * 4 * nvalid),
                "kernels_ms": {k: round(ms / n, 4) for k, (ms, n) in sorted(prof.items())},
                "kernels_ms_per_step": {k: round(ms / psteps, 4) for k, (ms, n) in sorted(prof.items())},
                "iteration_frac_of_hbm": round(5 * N * L * 4 / (dt / nsteps) / 1e9 / HBM_PEAK_GBS, 6), "last_totallkh": last}
@@ -412,6 +427,8 @@ def main():
     out = {}
     scheds = [("replay", capi.SCHED_REPLAY)] + ([] if args.no_keyed else [("keyed", capi.SCHED_KEYED)])
     for tag, sched in scheds:
+        if rank == 0:
+            note(tag + " schedule")
         ch = capi.HipChain(geno, an, mi, K, mode=2, type_freq=1, back_refl=1, rng_sched=sched, device=local)
         ch.setseeds(*seeds)
         ch.chain_init(np.array([ch.ran1() for _ in range(K)], dtype=np.float32))
@@ -438,8 +455,11 @@ def main():
     if rank == 0:
         cpu = cpu8 = None
         if world == 1 and not args.no_cpu:
+            note("cpu baseline: one reference process")
             cpu = cpu_baseline(geno, K, seeds)
+            note("cpu baseline: eight reference processes")
             cpu8 = cpu_baseline_concurrent(geno, K, seeds)
+        note("copy bandwidth")
         head = out["replay"]
         copy_gbs = round(capi.copy_bandwidth(local), 1)  # the fraction against a measured device-to-device copy as well (16-byte accesses)
         for o in out.values():
@@ -468,10 +488,13 @@ def main():
                              "note": "counter-based stream positions: bit-identical to the oracle's keyed schedule, statistically equivalent to the reference"}
         if world == 1 and not args.no_tetra:
             if not args.no_concurrent:
+                note("several chains on one GPU: threads, then processes")
                 line["concurrent_chains"] = concurrent_chains_leg(geno, an, mi, K, local, max(10, args.steps // 4), args.workload)
                 if cpu8 and line["concurrent_chains"].get("processes"):  # several chains on ONE GPU against eight host cores
                     line["concurrent_chains"]["processes"]["vs_cpu_8_processes"] = round(line["concurrent_chains"]["processes"]["chain_iterations_per_s"] / cpu8["value"], 1)
+            note("ploidy 4 (config 5)")
             line["ploidy4"] = tetra_leg(local, max(4, args.steps // 10), 2, not args.no_cpu)
+        note("done")
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

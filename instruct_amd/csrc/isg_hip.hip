@@ -37,6 +37,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <new>
 #include "../../include/instruct_hip.h"
 #include "isg_math.h"
 #include "isg_wh.h"
@@ -106,6 +107,27 @@ struct InbreedCtx;
 struct ResolveCtx;
 struct PDevCtx;
 struct SpecCtx;
+/* Host buffers that asynchronous copies read or write start on a page of their own and end on one: the runtime pins pageable memory
+ * page by page while a copy is in flight (and hipHostRegister pins whole pages), so two buffers of two chains that share a page -- chains
+ * run by threads of one process allocate theirs side by side in the heap -- would pin and release that page under each other. */
+template <class T>
+struct PageAlloc {
+	typedef T value_type;
+	PageAlloc() {}
+	template <class U> PageAlloc(const PageAlloc<U> &) {}
+	T *allocate(size_t n)
+	{
+		void *p = nullptr;
+		const size_t bytes = (n * sizeof(T) + 4095) & ~(size_t)4095;
+		if (posix_memalign(&p, 4096, bytes ? bytes : 4096)) throw std::bad_alloc();
+		return (T *)p;
+	}
+	void deallocate(T *p, size_t) { free(p); }
+	template <class U> bool operator==(const PageAlloc<U> &) const { return true; }
+	template <class U> bool operator!=(const PageAlloc<U> &) const { return false; }
+};
+template <class T> using hvec = std::vector<T, PageAlloc<T>>;
+
 struct isg_ctx {
 	isg_config cfg;
 	ResolveCtx *rs = nullptr; /* replay update_ZQ: start positions resolved block-wise (isg_resolve_hip.inc) */
@@ -118,15 +140,15 @@ struct isg_ctx {
 	hipStream_t stream;
 	/* host mirrors (reference layouts) */
 	std::vector<int> allelenum;
-	std::vector<double> freq;   /* [K][L][Amax] */
-	std::vector<double> qq;     /* [N][K] */
-	std::vector<int> qqnum;     /* [N][K] */
-	std::vector<int> gen;       /* [N] */
-	std::vector<double> S;      /* [K] */
-	std::vector<int> state;     /* [K] */
-	std::vector<double> indvlkh;
-	std::vector<int> cnt_h;     /* device order [L][Amax][K] */
-	std::vector<double> freq_stage; /* device order [L][Amax][KP] */
+	hvec<double> freq;   /* [K][L][Amax] */
+	hvec<double> qq;     /* [N][K] */
+	hvec<int> qqnum;     /* [N][K] */
+	hvec<int> gen;       /* [N] */
+	hvec<double> S;      /* [K] */
+	hvec<int> state;     /* [K] */
+	hvec<double> indvlkh;
+	hvec<int> cnt_h;     /* device order [L][Amax][K] */
+	hvec<double> freq_stage; /* device order [L][Amax][KP] */
 	double alpha, totallkh;
 	bool qq_dirty_host;         /* host qq newer than device */
 	/* stream */
@@ -175,7 +197,7 @@ struct isg_ctx {
 	long zq_fallbacks = 0;                /* sweeps redone by the single-workgroup kernel */
 	int *d_state;
 	double *d_ratios, *d_total;
-	std::vector<double> ratios_h;
+	hvec<double> ratios_h;
 	/* which host mirrors are current */
 	bool h_qq, h_gen, h_S, h_lkh;
 	/* CHAIN running means kept on the device (isg_store_*): qq, qq2 [N][K]; indvlkh, gen, gen2 [N]; freq, freq2 in the
