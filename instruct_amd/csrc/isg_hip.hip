@@ -567,16 +567,22 @@ __global__ void __launch_bounds__(BLOCK) k_loglik_int(DevView d)
 	const uint8_t *zrow = d.z + (size_t)i * rowb;
 	long long sAh = 0, sAm = 0, sBh = 0, sBm = 0, mAh = 0, mAm = 0, mBh = 0, mBm = 0;
 	unsigned n2 = 0, flags = 0;
-	for (unsigned j0 = threadIdx.x * ISG_LPT; j0 < Lp; j0 += BLOCK * ISG_LPT) {
-		const uint2 g = *(const uint2 *)(grow + (size_t)j0 * 2);
-		const uint2 zz = *(const uint2 *)(zrow + (size_t)j0 * 2);
+	/* consecutive lanes take consecutive loci (a lane's ISG_LPT loci lie BLOCK apart): a table row is locus innermost, so the lanes that read the
+	 * same row read one contiguous stretch of it -- a load instruction touches a few lines per row instead of a line per lane */
+	for (unsigned jb = 0; jb < Lp; jb += BLOCK * ISG_LPT) {
+		unsigned gw[ISG_LPT], zw[ISG_LPT];
 #pragma unroll
 		for (int l = 0; l < ISG_LPT; l++) {
-			const unsigned gw = (l < 2) ? g.x : g.y, zw = (l < 2) ? zz.x : zz.y;
-			const unsigned a0 = (gw >> (16 * (l & 1))) & 0xff, a1 = (gw >> (16 * (l & 1) + 8)) & 0xff;
-			const unsigned z0 = (zw >> (16 * (l & 1))) & 0xff, z1 = (zw >> (16 * (l & 1) + 8)) & 0xff;
+			const unsigned jl = jb + (unsigned)l * BLOCK + threadIdx.x;
+			gw[l] = (jl < Lp) ? *(const unsigned short *)(grow + (size_t)jl * 2) : 0xffffu;
+			zw[l] = (jl < Lp) ? *(const unsigned short *)(zrow + (size_t)jl * 2) : 0u;
+		}
+#pragma unroll
+		for (int l = 0; l < ISG_LPT; l++) {
+			const unsigned a0 = gw[l] & 0xff, a1 = gw[l] >> 8;
+			const unsigned z0 = zw[l] & 0xff, z1 = zw[l] >> 8;
 			const bool valid = (a0 != 0xff), same = (z0 == z1);
-			const unsigned j = j0 + (unsigned)l;
+			const unsigned j = jb + (unsigned)l * BLOCK + threadIdx.x;
 			const unsigned og = baseC + ((a0 * A + a1) * K + z0) * Lp + j;
 			const unsigned o0 = baseF + (a0 * K + z0) * Lp + j, o1 = baseF + (a1 * K + z1) * Lp + j;
 			unsigned offA = same ? og : o0;
