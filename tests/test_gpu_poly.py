@@ -375,10 +375,13 @@ def test_config5_full_size_properties(config5_data, sched):
     assert sig[0] == sig[1]
 
 
-def test_tetraploid_interval_resolver_and_device_update_P_take_the_sweeps():
+@pytest.mark.parametrize("strip", ["0", "1"])
+def test_tetraploid_interval_resolver_and_device_update_P_take_the_sweeps(strip, monkeypatch):
     """the generated case x_spec (pinned to the oracle line by line above): update_ZQ settled by the interval resolver (isg_spec_hip.inc),
-    update_P_auto's Dirichlets resolved on the device (isg_walk_hip.inc) -- not by their fallbacks"""
+    update_P_auto's Dirichlets resolved on the device (isg_walk_hip.inc) -- not by their fallbacks.  strip = 1: the expected counts from the
+    strip-per-wave kernel (k4_zexpect) instead of one lane per individual (k4_zexpect_ind)"""
     from instruct_amd import capi, synth
+    monkeypatch.setenv("INSTRUCT_ZEXPECT_STRIP", strip)
     N, L, K, A, miss = EXTRA["x_spec"][:5]
     obs, alleleid, allelenum = synth.code_tetraploid(extra_data("x_spec"))
     ch = capi.HipPolyChain(obs, alleleid, allelenum, K)
